@@ -1,0 +1,226 @@
+/*
+ * procgen_pt.h -- C ABI of libgpu_compute.so, the MI355X (gfx950) parallel-
+ * tempering library that takes the place of the reference's CUDA library of
+ * the same file name.
+ *
+ * Two layers:
+ *   1. The legacy entry point the unchanged F# host binds by P/Invoke
+ *      (reference src/GPU.Compute.fs:31-40), in the width that host really
+ *      marshals (double arrays; F# `float` is System.Double), plus an _f32
+ *      twin for callers that follow the CUDA source's `float*` signature
+ *      (reference src/gpu/parallel_tempering.cu:130-138).
+ *   2. A batched engine API (create / upload / run(steps) / download) that
+ *      keeps all replica state resident in HBM and runs whole swap intervals
+ *      per launch.  The legacy entry point is a thin wrapper over it.
+ *
+ * All pointers are plain host pointers unless a name starts with d_.
+ * No function throws or aborts across this boundary; every engine function
+ * returns a PT_* code and records a message for pt_last_error_string().
+ */
+#ifndef PROCGEN_PT_H
+#define PROCGEN_PT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes -------------------------------------------------------- */
+#define PT_OK                    0
+#define PT_ERR_INVALID_ARGUMENT  1
+#define PT_ERR_NO_DEVICE         2
+#define PT_ERR_HIP               3
+#define PT_ERR_NUMERIC_RANGE     4   /* a cost term was NaN/Inf or >= 2^62 */
+#define PT_ERR_CAPACITY          5   /* addEdge hit edge_capacity (treated as a no-op move) */
+#define PT_ERR_STREAM_EXHAUSTED  6   /* injected draw arrays shorter than the run */
+#define PT_ERR_OUT_OF_MEMORY     7
+
+/* Last error of the calling thread's most recent library call
+ * (additive exports; the reference library reports nothing at all:
+ * reference src/gpu/parallel_tempering.cu:130-248 returns void and checks no
+ * CUDA status). */
+int pt_last_error(void);
+const char *pt_last_error_string(void);
+
+/* ---- legacy entry points ------------------------------------------------ */
+
+/*
+ * Replaces reference src/gpu/parallel_tempering.cu:130-248 behind the extern
+ * declared at reference src/GPU.Compute.fs:31-40 and called from
+ * src/GPU.Wrappers.fs:112 (availability probe, all counts 0) and :315-323
+ * (once per iteration).
+ *
+ *   positions     [tempCount][nodeCount][3], in/out, chain-major
+ *   edges         [edgeCount][2] (from,to) of the shared topology, in
+ *   costs         [tempCount], out
+ *   temperatures  [tempCount], in, index 0 hottest
+ *   edgeCount     number of EDGES (as GPU.Wrappers.fs:293,321 passes it)
+ *
+ * One call is one iteration of ParallelTempering.run's loop body
+ * (reference src/ParallelTempering.Core.fs:162-177): every chain makes one
+ * Metropolis proposal (position perturbation; the shared topology cannot
+ * change through this ABI), and a sequential adjacent swap pass runs when the
+ * call counter is a multiple of swapFrequency(nodeCount).  The call counter
+ * and the random streams persist across calls with equal
+ * (nodeCount, edgeCount, tempCount) and restart when they change.
+ * Node 0 is the origin, node nodeCount-1 the terminal, every other node
+ * Standard 0.0 (node values do not cross this ABI).
+ * With all counts 0 it returns at once without touching the GPU state.
+ * On failure the outputs are left untouched; see pt_last_error().
+ */
+void parallel_tempering_step(double *positions, int *edges, double *costs, double *temperatures,
+                             int nodeCount, int edgeCount, int tempCount);
+
+/* Same contract with 32-bit floats, the width written in the CUDA source
+ * (reference src/gpu/parallel_tempering.cu:131-137). */
+void parallel_tempering_step_f32(float *positions, int *edges, float *costs, float *temperatures,
+                                 int nodeCount, int edgeCount, int tempCount);
+
+/* Drop the legacy entry points' persistent state (the reference never frees
+ * its static device buffers, src/gpu/parallel_tempering.cu:139-146). */
+void parallel_tempering_reset(void);
+
+/* ---- batched spatial-graph engine --------------------------------------- */
+
+typedef struct pt_graph_engine pt_graph_engine;
+
+enum { PT_MUT_ADAPTIVE = 0, PT_MUT_PERTURB_ONLY = 1 };
+enum { PT_RNG_PHILOX = 0, PT_RNG_INJECTED = 1 };
+enum { PT_NODE_ORIGIN = 0, PT_NODE_TERMINAL = 1, PT_NODE_STANDARD = 2 };
+
+/* Draws per chain per step: address k = 0 selector, 1 node / i / list index,
+ * 2..4 x,y,z offsets (addEdge: 2 = j), 5 accept.  Unused addresses are skipped. */
+#define PT_DRAWS_PER_STEP 6
+
+typedef struct pt_graph_config {
+    int32_t struct_size;        /* = sizeof(pt_graph_config) */
+    int32_t node_count;         /* N >= 1 */
+    int32_t edge_capacity;      /* per-replica capacity of the edge list */
+    int32_t temp_count;         /* T: temperatures per ladder held by THIS engine */
+    int32_t group_count;        /* G independent ladders; this engine runs G*T replicas */
+    int32_t swap_frequency;     /* f; <= 0 selects max(5, int(sqrt(N)*2)) (reference ParallelTempering.Core.fs:138-139) */
+    int32_t mutation_mode;      /* PT_MUT_* (reference Mutations.adaptive, ParallelTempering.Core.fs:67-79) */
+    int32_t rng_mode;           /* PT_RNG_* */
+    double weights[6];          /* connectivity, endpoint, edgeLength, collision, distribution, transitions
+                                   (reference ProceduralGeneration.fs:100-107) */
+    double target_edge_length;  /* 2.0  (reference ProceduralGeneration.fs:77) */
+    double min_distance;        /* 0.5  (reference ProceduralGeneration.fs:78) */
+    double min_distance_eps;    /* 0.001 (reference SpatialHash.fs:18) */
+    uint64_t philox_key;        /* used when seed is NULL */
+    const char *seed;           /* UTF-8; key = little-endian u64 of SHA-256(seed)[0..8], the bytes
+                                   HashRNG turns into a float (reference Deterministic.fs:14-22) */
+    int32_t device;             /* HIP device ordinal, < 0 = current device */
+    int32_t group_base;         /* global index of this engine's first ladder (multi-GPU sharding by ladder) */
+    int32_t ladder_temp_count;  /* global ladder length when ONE ladder is split over several engines
+                                   (then group_count must be 1); 0 = temp_count */
+    int32_t ladder_slot_base;   /* first temperature slot initially held by this engine's replicas */
+    int32_t block_threads;      /* workgroup size, 0 = default */
+    int32_t reserved;
+} pt_graph_config;
+
+/* Fill a config with the reference's defaults for N nodes, T temperatures. */
+void pt_graph_default_config(pt_graph_config *cfg, int32_t node_count, int32_t edge_capacity,
+                             int32_t temp_count, int32_t group_count);
+
+int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out);
+void pt_graph_destroy(pt_graph_engine *e);
+
+/*
+ * Upload initial state.  Replica (g, t) starts in temperature slot t of ladder g.
+ *   positions    [G][T][N][3] float
+ *   edges        [G][T][edge_stride][2] int32 in the reference's LIST order
+ *                (index 0 = list head = most recently added edge, the order
+ *                Marshaling.flattenEdges emits, reference GPU.Wrappers.fs:208-209)
+ *   edge_counts  [G][T]
+ *   node_kind    [G][N] PT_NODE_*           (NULL: node 0 origin, N-1 terminal, rest standard)
+ *   node_value   [G][N] Standard values     (NULL: 0.0)
+ *   temperatures [G][Tl] where Tl = ladder_temp_count or temp_count; index 0 hottest
+ * Resets the step counter to 0 and computes every replica's initial cost
+ * (reference ParallelTempering.Core.fs:157-160).
+ */
+int pt_graph_upload(pt_graph_engine *e, const float *positions, const int32_t *edges, int32_t edge_stride,
+                    const int32_t *edge_counts, const uint8_t *node_kind, const double *node_value,
+                    const double *temperatures);
+
+/* Injected draws (PT_RNG_INJECTED): chain_u [G][T][steps][PT_DRAWS_PER_STEP],
+ * swap_u [G][passes][Tl-1]; both doubles in [0,1), copied to the device. */
+int pt_graph_set_draws(pt_graph_engine *e, const double *chain_u, int64_t steps,
+                       const double *swap_u, int64_t passes);
+
+/* Optional per-step trace for parity tests: records [max_steps][G*T] of
+ * pt_trace_rec in slot order, and swap decisions [max_passes][G][Tl-1] bytes. */
+typedef struct pt_trace_rec {
+    int32_t kind;       /* 0 perturb, 1 addEdge, 2 removeEdge */
+    int32_t a, b;       /* perturb: node; add: i, j; remove: list index; -1 when not drawn */
+    int32_t flags;      /* bit0 no-op move, bit1 accept draw used, bit2 accepted, bit3 capacity hit */
+    int32_t reach0;     /* nodes reachable from node 0 in the proposed state */
+    int32_t reach_origin;
+    double delta;
+    double u;           /* accept draw or -1 */
+    double cost_after;
+} pt_trace_rec;
+int pt_graph_enable_trace(pt_graph_engine *e, int64_t max_steps, int64_t max_passes);
+int pt_graph_read_trace(pt_graph_engine *e, pt_trace_rec *steps_out, int64_t n_steps,
+                        uint8_t *swaps_out, int64_t n_passes);
+
+/*
+ * Advance every replica by `steps` iterations of ParallelTempering.run's loop
+ * (reference ParallelTempering.Core.fs:162-177), swap passes included
+ * (after every step whose index is a multiple of f, step 0 included).
+ * Asynchronous on the engine's stream; pt_graph_sync() waits.
+ */
+int pt_graph_run(pt_graph_engine *e, int64_t steps);
+int pt_graph_sync(pt_graph_engine *e);
+/* Index of the next step; the swap schedule and the draw addresses follow it
+ * (upload resets it to 0; resuming a run sets it back). */
+int pt_graph_set_step(pt_graph_engine *e, int64_t step);
+
+/* Split-ladder operation (one ladder over several engines/GPUs):
+ * pt_graph_run_interval advances to just before the next swap pass and
+ * returns; the caller all-gathers the energies and calls pt_graph_swap_pass
+ * with the full ladder's energies in REPLICA order (device pointer), which
+ * every engine applies identically.  d_energy_local exposes this engine's
+ * energies for the gather. */
+int pt_graph_run_to_swap_point(pt_graph_engine *e, int64_t max_steps, int64_t *steps_done, int32_t *swap_due);
+int pt_graph_local_energy_ptr(pt_graph_engine *e, double **d_energy_local, int32_t *count);
+int pt_graph_swap_pass(pt_graph_engine *e, const double *d_energy_all_replicas);
+
+/* Download in SLOT order (chain i of ladder g = temperature slot i, as the
+ * reference's chains array).  Any pointer may be NULL.  Synchronises.
+ *   positions [G][T][N][3], edges [G][T][edge_stride][2] list order,
+ *   edge_counts [G][T], costs [G][T], slots [G][T] = slot held by local replica t. */
+int pt_graph_download(pt_graph_engine *e, float *positions, int32_t *edges, int32_t edge_stride,
+                      int32_t *edge_counts, double *costs);
+int pt_graph_replica_slots(pt_graph_engine *e, int32_t *slot_of_replica_all);
+
+/* Cost terms of the current state of every local replica, slot order:
+ * [G*T][8] = conn, endpoint, edge, coll, dist, trans, total, reach0. */
+int pt_graph_cost_terms(pt_graph_engine *e, double *terms);
+
+/* Counters since upload: proposals made, accepted, swap attempts, swaps done,
+ * status bits (PT_ERR_* seen on device, as a bitmask 1<<code). */
+typedef struct pt_graph_stats {
+    int64_t steps, proposals, accepted, swap_attempts, swaps;
+    uint32_t status_bits;
+    uint32_t reserved;
+} pt_graph_stats;
+int pt_graph_get_stats(pt_graph_engine *e, pt_graph_stats *out);
+
+/* Timing of the step kernel: milliseconds and launches accumulated by HIP
+ * events on the engine's stream since the last reset (for the benchmark). */
+int pt_graph_kernel_time(pt_graph_engine *e, double *ms, int64_t *launches, int32_t reset);
+void *pt_graph_stream(pt_graph_engine *e);
+
+/* Unit-test hook: the exact fixed-point sum the engine uses, over n doubles. */
+int pt_debug_canonical_sum(const double *terms, int64_t n, double *out, int32_t *range_error);
+
+/* Scalar helpers mirroring the reference (ParallelTempering.Core.fs:88-95, :138-139). */
+int pt_geometric_ladder(double t_min, double t_max, int32_t n, double *out);
+int32_t pt_swap_frequency(int32_t node_count);
+uint64_t pt_seed_key(const char *seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,171 @@
+// Device-side building blocks shared by the graph and voxel engines:
+// exact (order-independent) fixed-point sums, Philox4x32-10, wave/block helpers.
+// gfx950 only: wavefront = 64 lanes.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PT_WAVE 64
+
+// ---------------------------------------------------------------------------
+// fx128: signed 128-bit fixed point, unit 2^-64.  Every cost sum is an integer
+// sum of terms truncated (toward zero) to this unit, so the result does not
+// depend on the order or grouping of the additions, and removing a term is the
+// exact inverse of adding it.
+// ---------------------------------------------------------------------------
+struct fx128 {
+    unsigned long long lo;
+    long long hi;
+};
+
+__device__ __forceinline__ fx128 fx_zero() { return fx128{0ull, 0ll}; }
+
+__device__ __forceinline__ void fx_add(fx128 &a, const fx128 &b)
+{
+    unsigned long long l = a.lo + b.lo;
+    a.hi += b.hi + (long long)(l < b.lo);
+    a.lo = l;
+}
+
+__device__ __forceinline__ fx128 fx_neg(fx128 a)
+{
+    fx128 r;
+    r.lo = ~a.lo + 1ull;
+    r.hi = (long long)(~(unsigned long long)a.hi + (unsigned long long)(r.lo == 0ull));
+    return r;
+}
+
+// trunc(|t| * 2^64) with the sign of t.  |t| must be < 2^62; otherwise (NaN and
+// infinities included) *err is set and the term counts as zero.
+__device__ __forceinline__ fx128 fx_from_double(double t, unsigned &err)
+{
+    unsigned long long bits = (unsigned long long)__double_as_longlong(t);
+    int e = (int)((bits >> 52) & 0x7ffu);
+    unsigned long long m = bits & ((1ull << 52) - 1ull);
+    fx128 r = fx_zero();
+    if (e >= 1023 + 62) { err = 1u; return r; }
+    if (e == 0) e = 1; else m |= (1ull << 52);
+    int sh = e - 1011;              // value * 2^64 = m * 2^sh, sh in [-1010, 73]
+    if (sh >= 64) { r.hi = (long long)(m << (sh - 64)); }
+    else if (sh > 0) { r.lo = m << sh; r.hi = (long long)(m >> (64 - sh)); }
+    else if (sh == 0) { r.lo = m; }
+    else if (sh > -64) { r.lo = m >> (-sh); }
+    if (bits >> 63) r = fx_neg(r);
+    return r;
+}
+
+// nearest double (ties to even) of a * 2^-64
+__device__ __forceinline__ double fx_to_double(fx128 a)
+{
+    bool neg = a.hi < 0;
+    if (neg) a = fx_neg(a);
+    unsigned long long hi = (unsigned long long)a.hi, lo = a.lo;
+    double r;
+    if (hi == 0ull) {
+        r = (double)lo * 0x1p-64;
+    } else {
+        int lz = __clzll((long long)hi);
+        unsigned long long top = lz ? ((hi << lz) | (lo >> (64 - lz))) : hi;
+        unsigned long long rest = lz ? (lo << lz) : lo;
+        top |= (unsigned long long)(rest != 0ull);      // sticky bit, far below the rounding position
+        r = ldexp((double)top, -lz);
+    }
+    return neg ? -r : r;
+}
+
+__device__ __forceinline__ fx128 fx_wave_reduce(fx128 v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        fx128 o;
+        o.lo = __shfl_down(v.lo, off, PT_WAVE);
+        o.hi = __shfl_down(v.hi, off, PT_WAVE);
+        fx_add(v, o);
+    }
+    return v;
+}
+
+// Add v into a 128-bit accumulator in LDS with two 64-bit atomics; the carry of
+// each low-word add is derived from the value that add returned, so any
+// interleaving of adders gives the exact total.
+__device__ __forceinline__ void fx_atomic_add_lds(fx128 *acc, const fx128 &v)
+{
+    unsigned long long old = atomicAdd(&acc->lo, v.lo);
+    unsigned long long carry = ((old + v.lo) < old) ? 1ull : 0ull;
+    atomicAdd((unsigned long long *)&acc->hi, (unsigned long long)v.hi + carry);
+}
+
+// every thread calls; lane 0 of each wave adds its wave's total into *acc
+__device__ __forceinline__ void fx_block_accumulate(fx128 *acc, fx128 v)
+{
+    v = fx_wave_reduce(v);
+    if ((threadIdx.x & (PT_WAVE - 1)) == 0) fx_atomic_add_lds(acc, v);
+}
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ double u53(uint32_t lo, uint32_t hi)
+{
+    return ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+// the p-th double of stream (stream_id, domain)
+__device__ __forceinline__ double philox_double(uint32_t k0, uint32_t k1, uint32_t stream_id, uint32_t domain,
+                                                unsigned long long p)
+{
+    unsigned long long q = p >> 1;
+    uint32_t w[4];
+    philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), stream_id, domain, k0, k1, w);
+    return (p & 1ull) ? u53(w[2], w[3]) : u53(w[0], w[1]);
+}
+
+// ---------------------------------------------------------------------------
+// block-wide exclusive scan of an int array in place (any address space),
+// len arbitrary.  tmp: LDS scratch of >= 17 ints.  All threads must call.
+// Returns the total.
+// ---------------------------------------------------------------------------
+__device__ inline int block_exclusive_scan(int *arr, int len, int *tmp)
+{
+    const int B = blockDim.x, tid = threadIdx.x;
+    const int chunk = (len + B - 1) / B;
+    const int beg = min(tid * chunk, len), end = min(beg + chunk, len);
+    int s = 0;
+    for (int i = beg; i < end; i++) s += arr[i];
+    // inclusive wave scan of s
+    int lane = tid & (PT_WAVE - 1), wv = tid / PT_WAVE, nw = (B + PT_WAVE - 1) / PT_WAVE;
+    int inc = s;
+#pragma unroll
+    for (int off = 1; off < PT_WAVE; off <<= 1) {
+        int o = __shfl_up(inc, off, PT_WAVE);
+        if (lane >= off) inc += o;
+    }
+    if (lane == PT_WAVE - 1) tmp[wv] = inc;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int w = 0; w < nw; w++) { int t = tmp[w]; tmp[w] = run; run += t; }
+        tmp[16] = run;
+    }
+    __syncthreads();
+    int base = tmp[wv] + inc - s;
+    int total = tmp[16];
+    for (int i = beg; i < end; i++) { int t = arr[i]; arr[i] = base; base += t; }
+    __syncthreads();
+    return total;
+}

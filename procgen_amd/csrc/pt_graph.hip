@@ -1,0 +1,645 @@
+// Host side of the batched spatial-graph engine (C ABI in include/procgen_pt.h).
+#include "pt_graph_kernels.h"
+#include "pt_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "pt_graph_kernels.hip.inc"
+
+namespace {
+
+constexpr size_t LDS_BUDGET = 160 * 1024 - 512;     // gfx950: 160 KiB per workgroup
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n)
+    {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        bytes = n ? n : 16;
+        return hipMalloc(&p, bytes);
+    }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+}  // namespace
+
+struct pt_graph_engine {
+    pt_graph_config cfg;
+    int N = 0, Ecap = 0, T = 0, G = 0, R = 0, Tl = 0, f = 0;
+    int device = 0, block = 0;
+    size_t lds_bytes = 0;
+    hipStream_t stream = nullptr;
+    GraphParams P;
+    SwapParams SP;
+    DevBuf px, py, pz, ea, eb, ebuf, ecount, kind, value, origin, terminal, rowend, adj, cost, temps,
+        slot_of_rep, rep_of_slot, cells, sorted, queue, bitmap, chain_u, swap_u, trace, swap_trace,
+        stats, swap_stats, status, terms;
+    long long step = 0;
+    long long trace_steps = 0, trace_passes = 0;
+    bool uploaded = false;
+    std::mutex mu;
+    // timing of the step kernel
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+    double timed_ms = 0.0;
+    long long timed_launches = 0;
+    bool timing = true;
+
+    ~pt_graph_engine()
+    {
+        for (auto &e : events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int drain_events(pt_graph_engine *e)
+{
+    for (size_t i = 0; i < e->events_used; i++) {
+        float ms = 0.f;
+        PT_HIP_TRY(hipEventSynchronize(e->events[i].second));
+        PT_HIP_TRY(hipEventElapsedTime(&ms, e->events[i].first, e->events[i].second));
+        e->timed_ms += ms;
+        e->timed_launches++;
+    }
+    e->events_used = 0;
+    return PT_OK;
+}
+
+int launch_steps(pt_graph_engine *e, long long step0, int nsteps)
+{
+    if (nsteps <= 0) return PT_OK;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (e->timing) {
+        if (e->events_used == e->events.size()) {
+            if (e->events.size() >= 4096) { int rc = drain_events(e); if (rc) return rc; }
+            else {
+                PT_HIP_TRY(hipEventCreate(&a)); PT_HIP_TRY(hipEventCreate(&b));
+                e->events.emplace_back(a, b);
+            }
+        }
+        a = e->events[e->events_used].first; b = e->events[e->events_used].second;
+        e->events_used++;
+        PT_HIP_TRY(hipEventRecord(a, e->stream));
+    }
+    hipLaunchKernelGGL(pt_graph_steps_kernel, dim3(e->R), dim3(e->block), e->lds_bytes, e->stream, e->P, step0, nsteps);
+    PT_HIP_TRY(hipGetLastError());
+    if (e->timing) PT_HIP_TRY(hipEventRecord(b, e->stream));
+    return PT_OK;
+}
+
+int launch_swap(pt_graph_engine *e, long long pass, const double *d_energy)
+{
+    SwapParams sp = e->SP;
+    sp.energy = d_energy;
+    int threads = 64, blocks = (e->G + threads - 1) / threads;
+    hipLaunchKernelGGL(pt_graph_swap_kernel, dim3(blocks), dim3(threads), 0, e->stream, sp, pass);
+    PT_HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void pt_graph_default_config(pt_graph_config *cfg, int32_t node_count, int32_t edge_capacity,
+                             int32_t temp_count, int32_t group_count)
+{
+    std::memset(cfg, 0, sizeof *cfg);
+    cfg->struct_size = (int32_t)sizeof *cfg;
+    cfg->node_count = node_count;
+    cfg->edge_capacity = edge_capacity;
+    cfg->temp_count = temp_count;
+    cfg->group_count = group_count;
+    cfg->swap_frequency = 0;
+    cfg->mutation_mode = PT_MUT_ADAPTIVE;
+    cfg->rng_mode = PT_RNG_PHILOX;
+    // reference src/ProceduralGeneration.fs:100-107
+    const double w[6] = {1.0, 1.0, 0.1, 0.5, 0.05, 0.1};
+    std::memcpy(cfg->weights, w, sizeof w);
+    cfg->target_edge_length = 2.0;
+    cfg->min_distance = 0.5;
+    cfg->min_distance_eps = 0.001;
+    cfg->philox_key = 0;
+    cfg->seed = nullptr;
+    cfg->device = -1;
+}
+
+int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
+{
+    pt::clear_error();
+    if (!cfg || !out) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null config or output pointer");
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(pt_graph_config))
+        return pt::set_error(PT_ERR_INVALID_ARGUMENT, "pt_graph_config.struct_size mismatch");
+    if (cfg->node_count < 1 || cfg->temp_count < 1 || cfg->group_count < 1 || cfg->edge_capacity < 0)
+        return pt::set_error(PT_ERR_INVALID_ARGUMENT, "node_count, temp_count, group_count must be >= 1");
+    if ((long long)cfg->group_count * cfg->temp_count > (1ll << 24))
+        return pt::set_error(PT_ERR_INVALID_ARGUMENT, "too many replicas");
+    int Tl = cfg->ladder_temp_count > 0 ? cfg->ladder_temp_count : cfg->temp_count;
+    if (Tl != cfg->temp_count && cfg->group_count != 1)
+        return pt::set_error(PT_ERR_INVALID_ARGUMENT, "a split ladder needs group_count == 1");
+    if (cfg->ladder_slot_base < 0 || cfg->ladder_slot_base + cfg->temp_count > Tl)
+        return pt::set_error(PT_ERR_INVALID_ARGUMENT, "ladder_slot_base + temp_count exceeds ladder_temp_count");
+    if (!(cfg->min_distance > 0.0) || !std::isfinite(cfg->min_distance))
+        return pt::set_error(PT_ERR_INVALID_ARGUMENT, "min_distance must be positive and finite");
+    if (cfg->mutation_mode != PT_MUT_ADAPTIVE && cfg->mutation_mode != PT_MUT_PERTURB_ONLY)
+        return pt::set_error(PT_ERR_INVALID_ARGUMENT, "unknown mutation_mode");
+    if (cfg->rng_mode != PT_RNG_PHILOX && cfg->rng_mode != PT_RNG_INJECTED)
+        return pt::set_error(PT_ERR_INVALID_ARGUMENT, "unknown rng_mode");
+    if (pt::device_count() < 1) return pt::set_error(PT_ERR_NO_DEVICE, "no HIP device");
+
+    int dev = cfg->device;
+    if (dev < 0) PT_HIP_TRY(hipGetDevice(&dev));
+    if (dev >= pt::device_count()) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    DeviceGuard guard(dev);
+
+    pt_graph_engine *e = new (std::nothrow) pt_graph_engine();
+    if (!e) return pt::set_error(PT_ERR_OUT_OF_MEMORY, "host allocation failed");
+    e->cfg = *cfg;
+    e->cfg.seed = nullptr;
+    e->device = dev;
+    e->N = cfg->node_count; e->Ecap = std::max(cfg->edge_capacity, 1); e->T = cfg->temp_count; e->G = cfg->group_count;
+    e->R = e->G * e->T; e->Tl = Tl;
+    e->f = cfg->swap_frequency > 0 ? cfg->swap_frequency : pt_swap_frequency(cfg->node_count);
+    uint64_t key = cfg->seed ? pt_seed_key(cfg->seed) : cfg->philox_key;
+
+    const int N = e->N, R = e->R;
+    // hash grid: M = 2^mb buckets >= 1.25 N, split over three axes, every axis >= 4 cells
+    int mb = 6;
+    while ((1ll << mb) < (long long)N + N / 4) mb++;
+    int gx = (mb + 2) / 3, gy = (mb - gx + 1) / 2, gz = mb - gx - gy;
+    const size_t M = (size_t)1 << mb;
+    const int nwords = (N + 31) / 32;
+
+    // workgroup size: enough lanes to cover max(N, E) a few elements each
+    int block = cfg->block_threads;
+    if (block <= 0) {
+        int work = std::max(N, e->Ecap);
+        block = 64;
+        while (block < 1024 && block * 8 < work) block *= 2;
+    }
+    block = std::min(1024, std::max(64, (block + 63) / 64 * 64));
+    e->block = block;
+
+    // LDS: header, then the visited bitmap, then the bucket array when they fit
+    size_t lds = sizeof(Shared);
+    int bitmap_in_lds = 0, cells_in_lds = 0;
+    size_t bm_bytes = (((size_t)nwords * 4 + 15) / 16) * 16;
+    if (lds + bm_bytes <= LDS_BUDGET) { bitmap_in_lds = 1; lds += bm_bytes; }
+    // several small replicas share a CU: keep each workgroup's LDS modest unless the graph is big
+    size_t cells_bytes = (M + 1) * 4;
+    size_t cells_cap = (block >= 1024) ? LDS_BUDGET : (LDS_BUDGET * block / 1024);
+    if (lds + cells_bytes <= cells_cap) { cells_in_lds = 1; lds += cells_bytes; }
+    e->lds_bytes = lds;
+
+    hipError_t herr = hipSuccess;
+    auto A = [&](DevBuf &b, size_t bytes) { if (herr == hipSuccess) herr = b.alloc(bytes); };
+    A(e->px, sizeof(float) * R * N); A(e->py, sizeof(float) * R * N); A(e->pz, sizeof(float) * R * N);
+    A(e->ea, sizeof(int) * (size_t)R * 2 * e->Ecap); A(e->eb, sizeof(int) * (size_t)R * 2 * e->Ecap);
+    A(e->ebuf, sizeof(int) * R); A(e->ecount, sizeof(int) * R);
+    A(e->kind, (size_t)e->G * N); A(e->value, sizeof(double) * (size_t)e->G * N);
+    A(e->origin, sizeof(int) * e->G); A(e->terminal, sizeof(int) * e->G);
+    A(e->rowend, sizeof(int) * (size_t)R * N); A(e->adj, sizeof(int) * (size_t)R * e->Ecap);
+    A(e->cost, sizeof(double) * R);
+    A(e->temps, sizeof(double) * (size_t)e->G * Tl);
+    A(e->slot_of_rep, sizeof(int) * (size_t)e->G * Tl); A(e->rep_of_slot, sizeof(int) * (size_t)e->G * Tl);
+    A(e->cells, cells_in_lds ? 16 : sizeof(int) * (size_t)R * (M + 1));
+    A(e->sorted, sizeof(int) * (size_t)R * N);
+    A(e->queue, sizeof(int) * (size_t)R * 2 * N);
+    A(e->bitmap, bitmap_in_lds ? 16 : sizeof(unsigned) * (size_t)R * nwords);
+    A(e->stats, sizeof(unsigned long long) * (size_t)R * 4);
+    A(e->swap_stats, sizeof(unsigned long long) * (size_t)e->G * 2);
+    A(e->status, sizeof(unsigned));
+    A(e->terms, sizeof(double) * (size_t)R * 8);
+    if (herr == hipSuccess) herr = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (herr == hipSuccess && lds > 64 * 1024) {
+        herr = hipFuncSetAttribute((const void *)pt_graph_steps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (herr == hipSuccess)
+            herr = hipFuncSetAttribute((const void *)pt_graph_init_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    if (herr != hipSuccess) {
+        int code = herr == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP;
+        std::string msg = std::string("engine allocation: ") + hipGetErrorString(herr);
+        (void)hipGetLastError();
+        delete e;
+        return pt::set_error(code, msg);
+    }
+
+    GraphParams &P = e->P;
+    std::memset(&P, 0, sizeof P);
+    P.N = N; P.Ecap = e->Ecap; P.T = e->T; P.G = e->G; P.Tl = Tl;
+    P.slot_base = cfg->ladder_slot_base; P.group_base = cfg->group_base;
+    P.mb = mb; P.gx = gx; P.gy = gy; P.gz = gz; P.nwords = nwords;
+    P.mutation_mode = cfg->mutation_mode; P.rng_mode = cfg->rng_mode;
+    P.cells_in_lds = cells_in_lds; P.bitmap_in_lds = bitmap_in_lds;
+    std::memcpy(P.w, cfg->weights, sizeof P.w);
+    P.target_len = cfg->target_edge_length; P.min_dist = cfg->min_distance; P.eps = cfg->min_distance_eps;
+    // cells a hair wider than min_distance: two points closer than min_distance are then always in
+    // adjacent cells whatever the rounding of the coordinate scaling
+    P.inv_cell = 1.0 / (cfg->min_distance * (1.0 + 0x1p-20));
+    P.key0 = (uint32_t)key; P.key1 = (uint32_t)(key >> 32);
+    P.px = e->px.as<float>(); P.py = e->py.as<float>(); P.pz = e->pz.as<float>();
+    P.ea = e->ea.as<int>(); P.eb = e->eb.as<int>(); P.ebuf = e->ebuf.as<int>(); P.ecount = e->ecount.as<int>();
+    P.kind = e->kind.as<uint8_t>(); P.value = e->value.as<double>();
+    P.origin_idx = e->origin.as<int>(); P.terminal_idx = e->terminal.as<int>();
+    P.rowend = e->rowend.as<int>(); P.adj = e->adj.as<int>(); P.cost = e->cost.as<double>();
+    P.temps = e->temps.as<double>(); P.slot_of_rep = e->slot_of_rep.as<int>();
+    P.cells = e->cells.as<int>(); P.sorted = e->sorted.as<int>(); P.queue = e->queue.as<int>();
+    P.bitmap = e->bitmap.as<unsigned>();
+    P.stats = e->stats.as<unsigned long long>(); P.status = e->status.as<unsigned>();
+    P.terms = nullptr;
+
+    SwapParams &S = e->SP;
+    std::memset(&S, 0, sizeof S);
+    S.G = e->G; S.Tl = Tl; S.group_base = cfg->group_base; S.rng_mode = cfg->rng_mode;
+    S.key0 = P.key0; S.key1 = P.key1;
+    S.temps = P.temps; S.slot_of_rep = e->slot_of_rep.as<int>(); S.rep_of_slot = e->rep_of_slot.as<int>();
+    S.swap_stats = e->swap_stats.as<unsigned long long>(); S.status = P.status;
+    *out = e;
+    return PT_OK;
+}
+
+void pt_graph_destroy(pt_graph_engine *e)
+{
+    if (!e) return;
+    DeviceGuard guard(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    delete e;
+}
+
+int pt_graph_upload(pt_graph_engine *e, const float *positions, const int32_t *edges, int32_t edge_stride,
+                    const int32_t *edge_counts, const uint8_t *node_kind, const double *node_value,
+                    const double *temperatures)
+{
+    pt::clear_error();
+    if (!e || !positions || !temperatures) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null engine, positions or temperatures");
+    if (!edge_counts && e->Ecap > 0 && edges) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "edges given without edge_counts");
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    const int N = e->N, R = e->R, G = e->G, T = e->T, Tl = e->Tl, Ecap = e->Ecap;
+
+    for (int i = 0; i < G * Tl; i++)
+        if (!(temperatures[i] > 0.0) || !std::isfinite(temperatures[i]))
+            return pt::set_error(PT_ERR_INVALID_ARGUMENT, "temperatures must be positive and finite");   // reference GPU.Wrappers.fs:278-279
+
+    std::vector<float> sx((size_t)R * N), sy((size_t)R * N), sz((size_t)R * N);
+    for (size_t i = 0; i < (size_t)R * N; i++) { sx[i] = positions[3 * i]; sy[i] = positions[3 * i + 1]; sz[i] = positions[3 * i + 2]; }
+    std::vector<int> ha((size_t)R * 2 * Ecap, 0), hb((size_t)R * 2 * Ecap, 0), hcount(R, 0), hbuf(R, 0);
+    for (int r = 0; r < R; r++) {
+        int ec = (edges && edge_counts) ? edge_counts[r] : 0;
+        if (ec < 0 || ec > Ecap || ec > edge_stride) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "edge count exceeds edge_capacity or edge_stride");
+        hcount[r] = ec;
+        const int32_t *src = edges + (size_t)r * edge_stride * 2;
+        for (int k = 0; k < ec; k++) {
+            int a = src[2 * k], b = src[2 * k + 1];
+            if (a < 0 || b < 0 || a >= N || b >= N) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "edge index out of bounds");  // reference GPU.Wrappers.fs:253-254
+            // list index k (0 = head) -> array index ec-1-k
+            ha[(size_t)r * 2 * Ecap + (ec - 1 - k)] = a;
+            hb[(size_t)r * 2 * Ecap + (ec - 1 - k)] = b;
+        }
+    }
+    std::vector<uint8_t> hk((size_t)G * N);
+    std::vector<double> hv((size_t)G * N, 0.0);
+    std::vector<int> horigin(G, -1), hterm(G, -1);
+    for (int g = 0; g < G; g++) {
+        for (int i = 0; i < N; i++) {
+            uint8_t k = node_kind ? node_kind[(size_t)g * N + i]
+                                  : (uint8_t)(i == 0 ? PT_NODE_ORIGIN : (i == N - 1 ? PT_NODE_TERMINAL : PT_NODE_STANDARD));
+            if (k > PT_NODE_STANDARD) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "unknown node kind");
+            hk[(size_t)g * N + i] = k;
+            if (node_value) hv[(size_t)g * N + i] = node_value[(size_t)g * N + i];
+            // first Origin / first Terminal (reference ProceduralGeneration.fs:50)
+            if (k == PT_NODE_ORIGIN && horigin[g] < 0) horigin[g] = i;
+            if (k == PT_NODE_TERMINAL && hterm[g] < 0) hterm[g] = i;
+        }
+    }
+    std::vector<int> sor((size_t)G * Tl), ros((size_t)G * Tl);
+    for (int g = 0; g < G; g++) for (int s = 0; s < Tl; s++) { sor[(size_t)g * Tl + s] = s; ros[(size_t)g * Tl + s] = s; }
+
+    hipStream_t st = e->stream;
+    PT_HIP_TRY(hipStreamSynchronize(st));
+    PT_HIP_TRY(hipMemcpy(e->px.p, sx.data(), sizeof(float) * sx.size(), hipMemcpyHostToDevice));
+    PT_HIP_TRY(hipMemcpy(e->py.p, sy.data(), sizeof(float) * sy.size(), hipMemcpyHostToDevice));
+    PT_HIP_TRY(hipMemcpy(e->pz.p, sz.data(), sizeof(float) * sz.size(), hipMemcpyHostToDevice));
+    PT_HIP_TRY(hipMemcpy(e->ea.p, ha.data(), sizeof(int) * ha.size(), hipMemcpyHostToDevice));
+    PT_HIP_TRY(hipMemcpy(e->eb.p, hb.data(), sizeof(int) * hb.size(), hipMemcpyHostToDevice));
+    PT_HIP_TRY(hipMemcpy(e->ebuf.p, hbuf.data(), sizeof(int) * R, hipMemcpyHostToDevice));
+    PT_HIP_TRY(hipMemcpy(e->ecount.p, hcount.data(), sizeof(int) * R, hipMemcpyHostToDevice));
+    PT_HIP_TRY(hipMemcpy(e->kind.p, hk.data(), hk.size(), hipMemcpyHostToDevice));
+    PT_HIP_TRY(hipMemcpy(e->value.p, hv.data(), sizeof(double) * hv.size(), hipMemcpyHostToDevice));
+    PT_HIP_TRY(hipMemcpy(e->origin.p, horigin.data(), sizeof(int) * G, hipMemcpyHostToDevice));
+    PT_HIP_TRY(hipMemcpy(e->terminal.p, hterm.data(), sizeof(int) * G, hipMemcpyHostToDevice));
+    PT_HIP_TRY(hipMemcpy(e->temps.p, temperatures, sizeof(double) * (size_t)G * Tl, hipMemcpyHostToDevice));
+    PT_HIP_TRY(hipMemcpy(e->slot_of_rep.p, sor.data(), sizeof(int) * sor.size(), hipMemcpyHostToDevice));
+    PT_HIP_TRY(hipMemcpy(e->rep_of_slot.p, ros.data(), sizeof(int) * ros.size(), hipMemcpyHostToDevice));
+    PT_HIP_TRY(hipMemset(e->stats.p, 0, e->stats.bytes));
+    PT_HIP_TRY(hipMemset(e->swap_stats.p, 0, e->swap_stats.bytes));
+    PT_HIP_TRY(hipMemset(e->status.p, 0, sizeof(unsigned)));
+    (void)T;
+
+    e->step = 0;
+    GraphParams P = e->P;
+    hipLaunchKernelGGL(pt_graph_init_kernel, dim3(R), dim3(e->block), e->lds_bytes, st, P, 1);
+    PT_HIP_TRY(hipGetLastError());
+    PT_HIP_TRY(hipStreamSynchronize(st));
+    e->uploaded = true;
+    return PT_OK;
+}
+
+int pt_graph_set_draws(pt_graph_engine *e, const double *chain_u, int64_t steps, const double *swap_u, int64_t passes)
+{
+    pt::clear_error();
+    if (!e || steps < 0 || passes < 0) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "bad draws arguments");
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    PT_HIP_TRY(hipStreamSynchronize(e->stream));
+    size_t nc = (size_t)e->G * e->Tl * (size_t)steps * PT_DRAWS_PER_STEP;
+    size_t ns = (size_t)e->G * (size_t)passes * (size_t)std::max(e->Tl - 1, 0);
+    PT_HIP_TRY(e->chain_u.alloc(sizeof(double) * nc));
+    PT_HIP_TRY(e->swap_u.alloc(sizeof(double) * ns));
+    if (nc) PT_HIP_TRY(hipMemcpy(e->chain_u.p, chain_u, sizeof(double) * nc, hipMemcpyHostToDevice));
+    if (ns) PT_HIP_TRY(hipMemcpy(e->swap_u.p, swap_u, sizeof(double) * ns, hipMemcpyHostToDevice));
+    e->P.chain_u = e->chain_u.as<double>(); e->P.draw_steps = steps;
+    e->SP.swap_u = e->swap_u.as<double>(); e->SP.draw_passes = passes;
+    return PT_OK;
+}
+
+int pt_graph_enable_trace(pt_graph_engine *e, int64_t max_steps, int64_t max_passes)
+{
+    pt::clear_error();
+    if (!e || max_steps < 0 || max_passes < 0) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "bad trace arguments");
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    PT_HIP_TRY(hipStreamSynchronize(e->stream));
+    size_t nt = (size_t)max_steps * e->G * e->Tl;
+    size_t ns = (size_t)max_passes * e->G * (size_t)std::max(e->Tl - 1, 0);
+    PT_HIP_TRY(e->trace.alloc(sizeof(pt_trace_rec) * nt));
+    PT_HIP_TRY(e->swap_trace.alloc(ns));
+    PT_HIP_TRY(hipMemset(e->trace.p, 0, e->trace.bytes));
+    PT_HIP_TRY(hipMemset(e->swap_trace.p, 0, e->swap_trace.bytes));
+    e->trace_steps = max_steps; e->trace_passes = max_passes;
+    e->P.trace = max_steps ? e->trace.as<pt_trace_rec>() : nullptr; e->P.trace_steps = max_steps;
+    e->SP.swap_trace = max_passes ? e->swap_trace.as<uint8_t>() : nullptr; e->SP.trace_passes = max_passes;
+    return PT_OK;
+}
+
+int pt_graph_read_trace(pt_graph_engine *e, pt_trace_rec *steps_out, int64_t n_steps, uint8_t *swaps_out, int64_t n_passes)
+{
+    pt::clear_error();
+    if (!e) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null engine");
+    if (n_steps > e->trace_steps || n_passes > e->trace_passes) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "trace request exceeds enabled size");
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    PT_HIP_TRY(hipStreamSynchronize(e->stream));
+    if (steps_out && n_steps)
+        PT_HIP_TRY(hipMemcpy(steps_out, e->trace.p, sizeof(pt_trace_rec) * (size_t)n_steps * e->G * e->Tl, hipMemcpyDeviceToHost));
+    if (swaps_out && n_passes && e->Tl > 1)
+        PT_HIP_TRY(hipMemcpy(swaps_out, e->swap_trace.p, (size_t)n_passes * e->G * (e->Tl - 1), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+// Steps [step, step+n) of the loop at reference src/ParallelTempering.Core.fs:162-177: the swap
+// pass follows every step whose index is a multiple of f.
+int pt_graph_run(pt_graph_engine *e, int64_t steps)
+{
+    pt::clear_error();
+    if (!e || steps < 0) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null engine or negative steps");
+    if (!e->uploaded) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "pt_graph_run before pt_graph_upload");
+    if (e->Tl != e->T) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "split ladder: use pt_graph_run_to_swap_point / pt_graph_swap_pass");
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    long long s = e->step, end = e->step + steps;
+    const long long f = e->f;
+    while (s < end) {
+        long long next_swap_step = ((s + f - 1) / f) * f;         // first multiple of f that is >= s
+        long long last = std::min(end - 1, next_swap_step);       // run through `last` inclusive
+        int n = (int)(last - s + 1);
+        int rc = launch_steps(e, s, n);
+        if (rc) return rc;
+        s = last + 1;
+        if (last == next_swap_step && e->Tl > 1) {
+            rc = launch_swap(e, last / f, e->cost.as<double>());
+            if (rc) return rc;
+        }
+    }
+    e->step = end;
+    return PT_OK;
+}
+
+// Set the index of the next step (the swap schedule and the draw addresses follow it).
+int pt_graph_set_step(pt_graph_engine *e, int64_t step)
+{
+    pt::clear_error();
+    if (!e || step < 0) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null engine or negative step");
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->step = step;
+    return PT_OK;
+}
+
+int pt_graph_run_to_swap_point(pt_graph_engine *e, int64_t max_steps, int64_t *steps_done, int32_t *swap_due)
+{
+    pt::clear_error();
+    if (!e || max_steps < 0) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null engine or negative steps");
+    if (!e->uploaded) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "run before upload");
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    long long s = e->step;
+    const long long f = e->f;
+    long long next_swap_step = ((s + f - 1) / f) * f;
+    long long last = std::min(s + max_steps - 1, next_swap_step);
+    int n = (int)(last - s + 1);
+    if (n > 0) { int rc = launch_steps(e, s, n); if (rc) return rc; e->step = last + 1; }
+    if (steps_done) *steps_done = n > 0 ? n : 0;
+    if (swap_due) *swap_due = (n > 0 && last == next_swap_step) ? 1 : 0;
+    return PT_OK;
+}
+
+int pt_graph_local_energy_ptr(pt_graph_engine *e, double **d_energy_local, int32_t *count)
+{
+    pt::clear_error();
+    if (!e || !d_energy_local) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null argument");
+    *d_energy_local = e->cost.as<double>();
+    if (count) *count = e->R;
+    return PT_OK;
+}
+
+int pt_graph_swap_pass(pt_graph_engine *e, const double *d_energy_all_replicas)
+{
+    pt::clear_error();
+    if (!e || !d_energy_all_replicas) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    if (e->step <= 0 || (e->step - 1) % e->f != 0) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "no swap pass is due at this step");
+    if (e->Tl < 2) return PT_OK;
+    return launch_swap(e, (e->step - 1) / e->f, d_energy_all_replicas);
+}
+
+int pt_graph_sync(pt_graph_engine *e)
+{
+    pt::clear_error();
+    if (!e) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null engine");
+    DeviceGuard guard(e->device);
+    PT_HIP_TRY(hipStreamSynchronize(e->stream));
+    return PT_OK;
+}
+
+int pt_graph_replica_slots(pt_graph_engine *e, int32_t *slot_of_replica_all)
+{
+    pt::clear_error();
+    if (!e || !slot_of_replica_all) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    PT_HIP_TRY(hipStreamSynchronize(e->stream));
+    PT_HIP_TRY(hipMemcpy(slot_of_replica_all, e->slot_of_rep.p, sizeof(int) * (size_t)e->G * e->Tl, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+// Output row of local replica (g, t): its slot minus the engine's first slot when the whole
+// ladder is local, else its replica position (a split ladder's caller reorders by slot itself).
+static int output_row(const pt_graph_engine *e, const std::vector<int> &sor, int g, int t)
+{
+    if (e->Tl == e->T) return g * e->T + sor[(size_t)g * e->Tl + t];
+    return g * e->T + t;
+}
+
+int pt_graph_download(pt_graph_engine *e, float *positions, int32_t *edges, int32_t edge_stride,
+                      int32_t *edge_counts, double *costs)
+{
+    pt::clear_error();
+    if (!e) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null engine");
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    PT_HIP_TRY(hipStreamSynchronize(e->stream));
+    const int N = e->N, R = e->R, G = e->G, T = e->T, Ecap = e->Ecap;
+    std::vector<int> sor((size_t)G * e->Tl);
+    PT_HIP_TRY(hipMemcpy(sor.data(), e->slot_of_rep.p, sizeof(int) * sor.size(), hipMemcpyDeviceToHost));
+    if (positions) {
+        std::vector<float> sx((size_t)R * N), sy((size_t)R * N), sz((size_t)R * N);
+        PT_HIP_TRY(hipMemcpy(sx.data(), e->px.p, sizeof(float) * sx.size(), hipMemcpyDeviceToHost));
+        PT_HIP_TRY(hipMemcpy(sy.data(), e->py.p, sizeof(float) * sy.size(), hipMemcpyDeviceToHost));
+        PT_HIP_TRY(hipMemcpy(sz.data(), e->pz.p, sizeof(float) * sz.size(), hipMemcpyDeviceToHost));
+        for (int g = 0; g < G; g++) for (int t = 0; t < T; t++) {
+            size_t src = ((size_t)g * T + t) * N, dst = (size_t)output_row(e, sor, g, t) * N;
+            for (int i = 0; i < N; i++) {
+                positions[3 * (dst + i)] = sx[src + i]; positions[3 * (dst + i) + 1] = sy[src + i]; positions[3 * (dst + i) + 2] = sz[src + i];
+            }
+        }
+    }
+    std::vector<int> hcount(R);
+    PT_HIP_TRY(hipMemcpy(hcount.data(), e->ecount.p, sizeof(int) * R, hipMemcpyDeviceToHost));
+    if (edge_counts)
+        for (int g = 0; g < G; g++) for (int t = 0; t < T; t++) edge_counts[output_row(e, sor, g, t)] = hcount[g * T + t];
+    if (edges) {
+        std::vector<int> ha((size_t)R * 2 * Ecap), hb((size_t)R * 2 * Ecap), hbuf(R);
+        PT_HIP_TRY(hipMemcpy(ha.data(), e->ea.p, sizeof(int) * ha.size(), hipMemcpyDeviceToHost));
+        PT_HIP_TRY(hipMemcpy(hb.data(), e->eb.p, sizeof(int) * hb.size(), hipMemcpyDeviceToHost));
+        PT_HIP_TRY(hipMemcpy(hbuf.data(), e->ebuf.p, sizeof(int) * R, hipMemcpyDeviceToHost));
+        for (int g = 0; g < G; g++) for (int t = 0; t < T; t++) {
+            int r = g * T + t, ec = hcount[r];
+            if (ec > edge_stride) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "edge_stride smaller than a replica's edge count");
+            size_t src = ((size_t)r * 2 + hbuf[r]) * Ecap;
+            int32_t *dst = edges + (size_t)output_row(e, sor, g, t) * edge_stride * 2;
+            for (int k = 0; k < ec; k++) { dst[2 * k] = ha[src + (ec - 1 - k)]; dst[2 * k + 1] = hb[src + (ec - 1 - k)]; }
+        }
+    }
+    if (costs) {
+        std::vector<double> hc(R);
+        PT_HIP_TRY(hipMemcpy(hc.data(), e->cost.p, sizeof(double) * R, hipMemcpyDeviceToHost));
+        for (int g = 0; g < G; g++) for (int t = 0; t < T; t++) costs[output_row(e, sor, g, t)] = hc[g * T + t];
+    }
+    return PT_OK;
+}
+
+int pt_graph_cost_terms(pt_graph_engine *e, double *terms)
+{
+    pt::clear_error();
+    if (!e || !terms) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null argument");
+    if (!e->uploaded) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "cost_terms before upload");
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    GraphParams P = e->P;
+    P.terms = e->terms.as<double>();
+    hipLaunchKernelGGL(pt_graph_init_kernel, dim3(e->R), dim3(e->block), e->lds_bytes, e->stream, P, 0);
+    PT_HIP_TRY(hipGetLastError());
+    PT_HIP_TRY(hipStreamSynchronize(e->stream));
+    std::vector<double> h((size_t)e->R * 8);
+    std::vector<int> sor((size_t)e->G * e->Tl);
+    PT_HIP_TRY(hipMemcpy(h.data(), e->terms.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    PT_HIP_TRY(hipMemcpy(sor.data(), e->slot_of_rep.p, sizeof(int) * sor.size(), hipMemcpyDeviceToHost));
+    for (int g = 0; g < e->G; g++) for (int t = 0; t < e->T; t++)
+        std::memcpy(terms + (size_t)output_row(e, sor, g, t) * 8, h.data() + ((size_t)g * e->T + t) * 8, sizeof(double) * 8);
+    return PT_OK;
+}
+
+int pt_graph_get_stats(pt_graph_engine *e, pt_graph_stats *out)
+{
+    pt::clear_error();
+    if (!e || !out) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    PT_HIP_TRY(hipStreamSynchronize(e->stream));
+    std::vector<unsigned long long> st((size_t)e->R * 4), sw((size_t)e->G * 2);
+    unsigned status = 0;
+    PT_HIP_TRY(hipMemcpy(st.data(), e->stats.p, sizeof(unsigned long long) * st.size(), hipMemcpyDeviceToHost));
+    PT_HIP_TRY(hipMemcpy(sw.data(), e->swap_stats.p, sizeof(unsigned long long) * sw.size(), hipMemcpyDeviceToHost));
+    PT_HIP_TRY(hipMemcpy(&status, e->status.p, sizeof status, hipMemcpyDeviceToHost));
+    std::memset(out, 0, sizeof *out);
+    out->steps = e->step;
+    for (int r = 0; r < e->R; r++) { out->proposals += (int64_t)st[(size_t)r * 4]; out->accepted += (int64_t)st[(size_t)r * 4 + 1]; }
+    for (int g = 0; g < e->G; g++) { out->swap_attempts += (int64_t)sw[(size_t)g * 2]; out->swaps += (int64_t)sw[(size_t)g * 2 + 1]; }
+    out->status_bits = status;
+    return PT_OK;
+}
+
+int pt_graph_kernel_time(pt_graph_engine *e, double *ms, int64_t *launches, int32_t reset)
+{
+    pt::clear_error();
+    if (!e) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null engine");
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    PT_HIP_TRY(hipStreamSynchronize(e->stream));
+    int rc = drain_events(e);
+    if (rc) return rc;
+    if (ms) *ms = e->timed_ms;
+    if (launches) *launches = e->timed_launches;
+    if (reset) { e->timed_ms = 0.0; e->timed_launches = 0; }
+    return PT_OK;
+}
+
+void *pt_graph_stream(pt_graph_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+// unit-test hook: exact fx128 sum of n doubles on the device
+int pt_debug_canonical_sum(const double *terms, int64_t n, double *out, int32_t *range_error)
+{
+    pt::clear_error();
+    if (!terms || !out || n < 0) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (pt::device_count() < 1) return pt::set_error(PT_ERR_NO_DEVICE, "no HIP device");
+    DevBuf x, o, er;
+    PT_HIP_TRY(x.alloc(sizeof(double) * (size_t)n)); PT_HIP_TRY(o.alloc(sizeof(double))); PT_HIP_TRY(er.alloc(sizeof(unsigned)));
+    if (n) PT_HIP_TRY(hipMemcpy(x.p, terms, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    PT_HIP_TRY(hipMemset(er.p, 0, sizeof(unsigned)));
+    hipLaunchKernelGGL(pt_debug_sum_kernel, dim3(1), dim3(256), 0, 0, x.as<double>(), (long long)n, o.as<double>(), er.as<unsigned>());
+    PT_HIP_TRY(hipGetLastError());
+    PT_HIP_TRY(hipDeviceSynchronize());
+    unsigned herr = 0;
+    PT_HIP_TRY(hipMemcpy(out, o.p, sizeof(double), hipMemcpyDeviceToHost));
+    PT_HIP_TRY(hipMemcpy(&herr, er.p, sizeof herr, hipMemcpyDeviceToHost));
+    if (range_error) *range_error = (int32_t)herr;
+    return PT_OK;
+}
+
+}  // extern "C"

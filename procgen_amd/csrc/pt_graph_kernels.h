@@ -1,0 +1,67 @@
+// Spatial-graph parallel-tempering kernels for gfx950: one workgroup per
+// (ladder, temperature) replica, whole swap intervals per launch.
+//
+// What one proposal does, following the reference CPU path
+// (reference src/ParallelTempering.Core.fs:122-133 optimizationStep):
+//   Mutations.adaptive (:67-79) -> full weighted cost of the proposed state
+//   (reference src/ProceduralGeneration.fs:73-81) -> Acceptance.acceptMove (:32-34).
+// The proposed state is never materialised: the cost is evaluated over the
+// current arrays plus a one-element overlay (moved node / added edge / removed
+// edge) and the arrays are edited only when the move is accepted.
+#pragma once
+
+#include "pt_device.h"
+#include "../../include/procgen_pt.h"
+
+struct GraphParams {
+    // sizes
+    int N, Ecap, T, G, Tl, slot_base, group_base;
+    int mb, gx, gy, gz;         // hash grid: M = 1<<mb buckets = (1<<gx)*(1<<gy)*(1<<gz)
+    int nwords;                 // visited bitmap words
+    int mutation_mode, rng_mode;
+    int cells_in_lds, bitmap_in_lds;
+    // cost
+    double w[6], target_len, min_dist, eps, inv_cell;
+    uint32_t key0, key1;
+    // state, replica-major
+    float *px, *py, *pz;        // [R][N]
+    int *ea, *eb;               // [R][2][Ecap]  ARRAY order (reverse of the reference's list order), double buffered
+    int *ebuf;                  // [R] which half is current
+    int *ecount;                // [R]
+    const uint8_t *kind;        // [G][N]
+    const double *value;        // [G][N]
+    const int *origin_idx, *terminal_idx;   // [G]
+    int *rowend, *adj;          // CSR of the current edges: row u = adj[rowend[u-1] .. rowend[u])
+    double *cost;               // [R]
+    const double *temps;        // [G][Tl]
+    const int *slot_of_rep;     // [G][Tl]
+    // scratch, replica-major
+    int *cells;                 // [R][M+1]  (when not in LDS)
+    int *sorted;                // [R][N]
+    int *queue;                 // [R][2][N]
+    unsigned *bitmap;           // [R][nwords] (when not in LDS)
+    // draws
+    const double *chain_u;      // [G][Tl][draw_steps][6]
+    long long draw_steps;
+    // outputs
+    pt_trace_rec *trace;        // [trace_steps][G*Tl]
+    long long trace_steps;
+    unsigned long long *stats;  // [R][4] proposals, accepted, -, -
+    unsigned *status;           // bitmask of PT_ERR_* seen
+    double *terms;              // [R][8] or null
+};
+
+struct SwapParams {
+    int G, Tl, group_base, rng_mode;
+    uint32_t key0, key1;
+    const double *temps;        // [G][Tl]
+    int *slot_of_rep;           // [G][Tl]
+    int *rep_of_slot;           // [G][Tl]
+    const double *energy;       // [G][Tl] replica order
+    const double *swap_u;       // [G][passes][Tl-1]
+    long long draw_passes;
+    uint8_t *swap_trace;        // [trace_passes][G][Tl-1]
+    long long trace_passes;
+    unsigned long long *swap_stats; // [G][2] attempts, swaps
+    unsigned *status;
+};

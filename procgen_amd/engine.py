@@ -1,0 +1,157 @@
+"""GraphEngine: the batched spatial-graph parallel-tempering engine over the C ABI.
+
+Thin: every method is one call into libgpu_compute.so.  Arrays are numpy on the
+host side; all replica state lives in HBM between calls.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import native as nt
+
+
+class GraphEngine:
+    def __init__(self, node_count, edge_capacity, temp_count, group_count=1, *, swap_frequency=0,
+                 mutation_mode=nt.MUT_ADAPTIVE, rng_mode=nt.RNG_PHILOX, weights=None, seed=None,
+                 philox_key=0, device=-1, group_base=0, ladder_temp_count=0, ladder_slot_base=0,
+                 block_threads=0, target_edge_length=2.0, min_distance=0.5, min_distance_eps=0.001):
+        self.L = nt.load()
+        cfg = nt.GraphConfig()
+        self.L.pt_graph_default_config(C.byref(cfg), node_count, edge_capacity, temp_count, group_count)
+        cfg.swap_frequency = swap_frequency
+        cfg.mutation_mode = mutation_mode
+        cfg.rng_mode = rng_mode
+        if weights is not None:
+            for i, w in enumerate(weights):
+                cfg.weights[i] = w
+        cfg.target_edge_length = target_edge_length
+        cfg.min_distance = min_distance
+        cfg.min_distance_eps = min_distance_eps
+        cfg.philox_key = philox_key
+        self._seed = seed.encode("utf-8") if seed is not None else None
+        cfg.seed = self._seed
+        cfg.device = device
+        cfg.group_base = group_base
+        cfg.ladder_temp_count = ladder_temp_count
+        cfg.ladder_slot_base = ladder_slot_base
+        cfg.block_threads = block_threads
+        self.cfg = cfg
+        self.N, self.Ecap, self.T, self.G = node_count, max(edge_capacity, 1), temp_count, group_count
+        self.Tl = ladder_temp_count or temp_count
+        self.R = self.G * self.T
+        self.swap_frequency = swap_frequency if swap_frequency > 0 else nt.swap_frequency(node_count)
+        h = C.c_void_p()
+        nt.check(self.L.pt_graph_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pt_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- state ----------------------------------------------------------------
+    def upload(self, positions, edges, edge_counts, temperatures, node_kind=None, node_value=None):
+        """positions [G,T,N,3]; edges [G,T,stride,2] list order; edge_counts [G,T]; temperatures [G,Tl]."""
+        pos = np.ascontiguousarray(positions, np.float32).reshape(self.R, self.N, 3)
+        temps = np.ascontiguousarray(temperatures, np.float64).reshape(self.G, self.Tl)
+        if edges is None:
+            ed, stride, ec = None, 0, np.zeros(self.R, np.int32)
+        else:
+            ed = np.ascontiguousarray(edges, np.int32)
+            stride = ed.size // (self.R * 2) if self.R else 0
+            ed = ed.reshape(self.R, stride, 2)
+            ec = np.ascontiguousarray(edge_counts, np.int32).reshape(self.R)
+        kind = None if node_kind is None else np.ascontiguousarray(node_kind, np.uint8).reshape(self.G, self.N)
+        val = None if node_value is None else np.ascontiguousarray(node_value, np.float64).reshape(self.G, self.N)
+        nt.check(self.L.pt_graph_upload(self.h, nt.ptr(pos), nt.ptr(ed), stride, nt.ptr(ec), nt.ptr(kind),
+                                        nt.ptr(val), nt.ptr(temps)))
+
+    def set_draws(self, chain_u, swap_u):
+        """chain_u [G,Tl,steps,6]; swap_u [G,passes,Tl-1]."""
+        cu = np.ascontiguousarray(chain_u, np.float64)
+        steps = cu.size // (self.G * self.Tl * nt.DRAWS_PER_STEP)
+        su = np.ascontiguousarray(swap_u, np.float64)
+        passes = su.size // (self.G * max(self.Tl - 1, 1)) if self.Tl > 1 else 0
+        nt.check(self.L.pt_graph_set_draws(self.h, nt.ptr(cu), steps, nt.ptr(su), passes))
+
+    def enable_trace(self, max_steps, max_passes):
+        self._trace_steps, self._trace_passes = max_steps, max_passes
+        nt.check(self.L.pt_graph_enable_trace(self.h, max_steps, max_passes))
+
+    def read_trace(self, n_steps, n_passes):
+        tr = np.zeros((n_steps, self.G * self.Tl), nt.TRACE_DTYPE)
+        sw = np.zeros((n_passes, self.G, max(self.Tl - 1, 0)), np.uint8)
+        nt.check(self.L.pt_graph_read_trace(self.h, nt.ptr(tr), n_steps, nt.ptr(sw), n_passes))
+        return tr, sw
+
+    def run(self, steps):
+        nt.check(self.L.pt_graph_run(self.h, steps))
+
+    def sync(self):
+        nt.check(self.L.pt_graph_sync(self.h))
+
+    def set_step(self, step):
+        nt.check(self.L.pt_graph_set_step(self.h, step))
+
+    def run_to_swap_point(self, max_steps):
+        done, due = C.c_int64(0), C.c_int32(0)
+        nt.check(self.L.pt_graph_run_to_swap_point(self.h, max_steps, C.byref(done), C.byref(due)))
+        return done.value, bool(due.value)
+
+    def local_energy_ptr(self):
+        p, n = C.c_void_p(), C.c_int32(0)
+        nt.check(self.L.pt_graph_local_energy_ptr(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def swap_pass(self, d_energy_all):
+        nt.check(self.L.pt_graph_swap_pass(self.h, C.c_void_p(d_energy_all)))
+
+    def download(self, positions=True, edges=True, costs=True):
+        pos = np.zeros((self.G, self.T, self.N, 3), np.float32) if positions else None
+        ed = np.zeros((self.G, self.T, self.Ecap, 2), np.int32) if edges else None
+        ec = np.zeros((self.G, self.T), np.int32)
+        co = np.zeros((self.G, self.T), np.float64) if costs else None
+        nt.check(self.L.pt_graph_download(self.h, nt.ptr(pos), nt.ptr(ed), self.Ecap, nt.ptr(ec), nt.ptr(co)))
+        return dict(pos=pos, edges=ed, ecount=ec, cost=co)
+
+    def replica_slots(self):
+        s = np.zeros((self.G, self.Tl), np.int32)
+        nt.check(self.L.pt_graph_replica_slots(self.h, nt.ptr(s)))
+        return s
+
+    def cost_terms(self):
+        t = np.zeros((self.G, self.T, 8), np.float64)
+        nt.check(self.L.pt_graph_cost_terms(self.h, nt.ptr(t)))
+        return t
+
+    def stats(self):
+        s = nt.GraphStats()
+        nt.check(self.L.pt_graph_get_stats(self.h, C.byref(s)))
+        return dict(steps=s.steps, proposals=s.proposals, accepted=s.accepted,
+                    swap_attempts=s.swap_attempts, swaps=s.swaps, status_bits=s.status_bits)
+
+    def kernel_time(self, reset=False):
+        ms, n = C.c_double(0), C.c_int64(0)
+        nt.check(self.L.pt_graph_kernel_time(self.h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+
+def canonical_sum(terms):
+    """Exact fixed-point sum on the device (unit-test hook)."""
+    L = nt.load()
+    x = np.ascontiguousarray(terms, np.float64)
+    out, err = C.c_double(0), C.c_int32(0)
+    nt.check(L.pt_debug_canonical_sum(nt.ptr(x), x.size, C.byref(out), C.byref(err)))
+    return out.value, err.value

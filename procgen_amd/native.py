@@ -1,0 +1,135 @@
+"""ctypes binding of libgpu_compute.so (C ABI: include/procgen_pt.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this
+module raises.  Build the library with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C procgen_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "lib", "libgpu_compute.so")
+
+PT_OK = 0
+ERR_NAMES = {1: "INVALID_ARGUMENT", 2: "NO_DEVICE", 3: "HIP", 4: "NUMERIC_RANGE", 5: "CAPACITY",
+             6: "STREAM_EXHAUSTED", 7: "OUT_OF_MEMORY"}
+MUT_ADAPTIVE, MUT_PERTURB_ONLY = 0, 1
+RNG_PHILOX, RNG_INJECTED = 0, 1
+NODE_ORIGIN, NODE_TERMINAL, NODE_STANDARD = 0, 1, 2
+DRAWS_PER_STEP = 6
+
+
+class PtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"PT_ERR_{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class GraphConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("node_count", C.c_int32), ("edge_capacity", C.c_int32),
+                ("temp_count", C.c_int32), ("group_count", C.c_int32), ("swap_frequency", C.c_int32),
+                ("mutation_mode", C.c_int32), ("rng_mode", C.c_int32), ("weights", C.c_double * 6),
+                ("target_edge_length", C.c_double), ("min_distance", C.c_double),
+                ("min_distance_eps", C.c_double), ("philox_key", C.c_uint64), ("seed", C.c_char_p),
+                ("device", C.c_int32), ("group_base", C.c_int32), ("ladder_temp_count", C.c_int32),
+                ("ladder_slot_base", C.c_int32), ("block_threads", C.c_int32), ("reserved", C.c_int32)]
+
+
+class GraphStats(C.Structure):
+    _fields_ = [("steps", C.c_int64), ("proposals", C.c_int64), ("accepted", C.c_int64),
+                ("swap_attempts", C.c_int64), ("swaps", C.c_int64), ("status_bits", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+TRACE_DTYPE = np.dtype([("kind", "<i4"), ("a", "<i4"), ("b", "<i4"), ("flags", "<i4"),
+                        ("reach0", "<i4"), ("reach_origin", "<i4"), ("delta", "<f8"),
+                        ("u", "<f8"), ("cost_after", "<f8")])
+
+# every symbol include/procgen_pt.h declares
+EXPORTS = [
+    "pt_last_error", "pt_last_error_string",
+    "parallel_tempering_step", "parallel_tempering_step_f32", "parallel_tempering_reset",
+    "pt_graph_default_config", "pt_graph_create", "pt_graph_destroy", "pt_graph_upload",
+    "pt_graph_set_draws", "pt_graph_enable_trace", "pt_graph_read_trace", "pt_graph_run",
+    "pt_graph_sync", "pt_graph_set_step", "pt_graph_run_to_swap_point", "pt_graph_local_energy_ptr",
+    "pt_graph_swap_pass", "pt_graph_download", "pt_graph_replica_slots", "pt_graph_cost_terms",
+    "pt_graph_get_stats", "pt_graph_kernel_time", "pt_graph_stream", "pt_debug_canonical_sum",
+    "pt_geometric_ladder", "pt_swap_frequency", "pt_seed_key",
+]
+
+_lib = None
+
+
+def load():
+    """Load the library (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} is missing: build it first (make -C procgen_amd/csrc)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.pt_last_error.restype = C.c_int
+    L.pt_last_error_string.restype = C.c_char_p
+    L.parallel_tempering_step.restype = None
+    L.parallel_tempering_step.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]
+    L.parallel_tempering_step_f32.restype = None
+    L.parallel_tempering_step_f32.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]
+    L.parallel_tempering_reset.restype = None
+    L.pt_graph_default_config.restype = None
+    L.pt_graph_default_config.argtypes = [C.POINTER(GraphConfig), i32, i32, i32, i32]
+    L.pt_graph_create.argtypes = [C.POINTER(GraphConfig), C.POINTER(vp)]
+    L.pt_graph_destroy.restype = None
+    L.pt_graph_destroy.argtypes = [vp]
+    L.pt_graph_upload.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp]
+    L.pt_graph_set_draws.argtypes = [vp, vp, i64, vp, i64]
+    L.pt_graph_enable_trace.argtypes = [vp, i64, i64]
+    L.pt_graph_read_trace.argtypes = [vp, vp, i64, vp, i64]
+    L.pt_graph_run.argtypes = [vp, i64]
+    L.pt_graph_sync.argtypes = [vp]
+    L.pt_graph_set_step.argtypes = [vp, i64]
+    L.pt_graph_run_to_swap_point.argtypes = [vp, i64, C.POINTER(i64), C.POINTER(i32)]
+    L.pt_graph_local_energy_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(i32)]
+    L.pt_graph_swap_pass.argtypes = [vp, vp]
+    L.pt_graph_download.argtypes = [vp, vp, vp, i32, vp, vp]
+    L.pt_graph_replica_slots.argtypes = [vp, vp]
+    L.pt_graph_cost_terms.argtypes = [vp, vp]
+    L.pt_graph_get_stats.argtypes = [vp, C.POINTER(GraphStats)]
+    L.pt_graph_kernel_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), i32]
+    L.pt_graph_stream.restype = vp
+    L.pt_graph_stream.argtypes = [vp]
+    L.pt_debug_canonical_sum.argtypes = [vp, i64, C.POINTER(dbl), C.POINTER(i32)]
+    L.pt_geometric_ladder.restype = C.c_int
+    L.pt_geometric_ladder.argtypes = [dbl, dbl, i32, C.POINTER(dbl)]
+    L.pt_swap_frequency.restype = i32
+    L.pt_swap_frequency.argtypes = [i32]
+    L.pt_seed_key.restype = C.c_uint64
+    L.pt_seed_key.argtypes = [C.c_char_p]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != PT_OK:
+        L = load()
+        raise PtError(rc, (L.pt_last_error_string() or b"").decode())
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def geometric_ladder(t_min, t_max, n):
+    out = (C.c_double * max(n, 1))()
+    k = load().pt_geometric_ladder(t_min, t_max, n, out)
+    return np.array(out[:k])
+
+
+def swap_frequency(n):
+    return int(load().pt_swap_frequency(n))
+
+
+def seed_key(seed: str) -> int:
+    return int(load().pt_seed_key(seed.encode("utf-8")))

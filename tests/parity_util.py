@@ -1,0 +1,80 @@
+"""Shared helpers of the GPU parity tests: run the same job through the HIP
+engine (C ABI) and through the CPU oracle, and compare."""
+import numpy as np
+
+import oracle_binding as ob
+from procgen_amd import native as nt
+from procgen_amd.engine import GraphEngine
+
+TRACE_FIELDS = ["kind", "a", "b", "flags", "reach0", "reach_origin", "delta", "u", "cost_after"]
+
+
+def oracle_run(wl, iters, swap_freq, *, seed=None, key=None, mutation_mode=ob.MUT_ADAPTIVE, weights=None,
+               chain_u=None, swap_u=None, algo=ob.ALGO_OPTIMISED, sum_mode=ob.SUM_CANONICAL, trace=True, threads=1):
+    """Run every ladder of a workload through the oracle.  Returns a list per ladder."""
+    if key is None and seed is not None:
+        key = int(ob.lib().og_seed_key(seed.encode()))
+    cfg = ob.default_config(sum_mode, algo, mutation_mode, weights)
+    out = []
+    T = wl["temps"]
+    for g in range(wl["groups"]):
+        kw = {}
+        if chain_u is not None:
+            kw = dict(chain_u=chain_u[g].reshape(T, -1), swap_u=swap_u[g].reshape(-1))
+        out.append(ob.run(wl["pos"][g], wl["edges"][g], wl["ecount"][g], wl["kind"][g], wl["value"][g],
+                          wl["temperatures"][g], iters, swap_freq, cfg, key=key, stream_base=g * T,
+                          swap_stream_id=g, trace=trace, threads=threads, **kw))
+    return out
+
+
+def gpu_run(wl, iters, swap_freq, *, seed=None, key=0, mutation_mode=nt.MUT_ADAPTIVE, weights=None,
+            chain_u=None, swap_u=None, trace=True, block_threads=0, chunks=None):
+    eng = GraphEngine(wl["n"], wl["ecap"], wl["temps"], wl["groups"], swap_frequency=swap_freq,
+                      mutation_mode=mutation_mode, weights=weights, seed=seed, philox_key=key,
+                      rng_mode=nt.RNG_INJECTED if chain_u is not None else nt.RNG_PHILOX,
+                      block_threads=block_threads)
+    try:
+        eng.upload(wl["pos"], wl["edges"], wl["ecount"], wl["temperatures"], wl["kind"], wl["value"])
+        init_cost = eng.download(positions=False, edges=False)["cost"]
+        if chain_u is not None:
+            eng.set_draws(chain_u, swap_u)
+        passes = (iters + swap_freq - 1) // swap_freq if swap_freq > 0 else 0
+        if trace:
+            eng.enable_trace(iters, passes)
+        for c in (chunks or [iters]):
+            eng.run(c)
+        eng.sync()
+        res = eng.download()
+        res["init_cost"] = init_cost
+        res["stats"] = eng.stats()
+        if trace:
+            res["trace"], res["swap_trace"] = eng.read_trace(iters, passes)
+        res["terms"] = eng.cost_terms()
+        res["slots"] = eng.replica_slots()
+        return res
+    finally:
+        eng.close()
+
+
+def assert_same_run(wl, gpu, orc, iters, *, trace=True):
+    """Bit-exact comparison of a GPU run with the oracle's canonical-sum run."""
+    T = wl["temps"]
+    for g in range(wl["groups"]):
+        o = orc[g]
+        assert o["err"] == 0
+        if trace:
+            gt = gpu["trace"][:, g * T:(g + 1) * T]
+            for f in TRACE_FIELDS:
+                if not np.array_equal(gt[f], o["trace"][f]):
+                    bad = np.argwhere(gt[f] != o["trace"][f])[0]
+                    raise AssertionError(
+                        f"ladder {g}: trace field {f!r} first differs at step {bad[0]} chain {bad[1]}: "
+                        f"gpu {gt[bad[0], bad[1]]} oracle {o['trace'][bad[0], bad[1]]}")
+            assert np.array_equal(gpu["swap_trace"][:, g, :], o["swap_trace"]), f"ladder {g}: swap decisions differ"
+        assert np.array_equal(gpu["ecount"][g], o["ecount"]), f"ladder {g}: edge counts differ"
+        assert np.array_equal(gpu["cost"][g], o["cost"]), f"ladder {g}: costs differ {gpu['cost'][g]} vs {o['cost']}"
+        assert np.array_equal(gpu["pos"][g], o["pos"]), f"ladder {g}: positions differ"
+        for t in range(T):
+            ec = o["ecount"][t]
+            assert np.array_equal(gpu["edges"][g, t, :ec], o["edges"][t, :ec]), f"ladder {g} chain {t}: edge lists differ"
+    assert gpu["stats"]["status_bits"] == 0

@@ -1,0 +1,47 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/procgen_pt.h declares."""
+import os
+import re
+
+import pytest
+
+from procgen_amd import native as nt
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "procgen_pt.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b((?:pt_|parallel_tempering)\w*)\s*\(", src))
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = nt.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/procgen_pt.h but not exported"
+    assert sorted(nt.EXPORTS) == declared
+
+
+def test_scalar_helpers_match_reference_values():
+    # reference src/ParallelTempering.Core.fs:88-95, :138-139
+    lad = nt.geometric_ladder(0.5, 5.0, 5)
+    assert lad == pytest.approx([5.0, 2.8117066259517456, 1.5811388300841898, 0.8891397050194614, 0.5], rel=1e-14)
+    assert list(nt.geometric_ladder(0.5, 5.0, 1)) == [5.0]
+    assert [nt.swap_frequency(n) for n in (1, 20, 1000, 10000, 1000000)] == [5, 8, 63, 200, 2000]
+
+
+def test_seed_key_is_sha256_prefix():
+    import hashlib
+    import struct
+    for s in ["", "abc", "procgen-bench/c2/0", "x" * 200]:
+        assert nt.seed_key(s) == struct.unpack("<Q", hashlib.sha256(s.encode()).digest()[:8])[0]
+
+
+def test_probe_call_is_harmless_without_gpu():
+    # reference src/GPU.Wrappers.fs:112: parallel_tempering_step([||],[||],[||],[||],0,0,0)
+    lib = nt.load()
+    lib.parallel_tempering_step(None, None, None, None, 0, 0, 0)
+    assert lib.pt_last_error() == 0

@@ -1,0 +1,219 @@
+"""GPU parity tests of the spatial-graph engine: the HIP path (through the C ABI)
+against the CPU oracle on identical inputs and identical random draws.
+
+Bar: everything bit-exact against the oracle's canonical-sum mode (BFS counts,
+proposals, accept decisions, swap decisions, positions, edge lists AND costs);
+against the oracle's reference-order (sequential fp64) mode costs agree to
+1e-12 relative.  The oracle itself is a restatement of the F# path pinned only
+by the reference's scalar known-answer values (tests/test_oracle_kat.py); whole
+trajectories are "parity unpinned" beyond that.
+"""
+import fractions
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import parity_util as pu
+from procgen_amd import native as nt
+from procgen_amd import workloads as wlm
+from procgen_amd.engine import GraphEngine, canonical_sum
+
+pytestmark = pytest.mark.gpu
+
+
+def _exact_sum_py(x):
+    tot = 0
+    for t in x:
+        fr = fractions.Fraction(float(t))
+        q = int(abs(fr) * (1 << 64))          # trunc toward zero of |t| * 2^64
+        tot += -q if fr < 0 else q
+    return float(fractions.Fraction(tot, 1 << 64))
+
+
+def test_fixed_point_sum_matches_big_integer_arithmetic(gpu_lib):
+    rng = np.random.default_rng(1)
+    cases = [
+        rng.random(1000) * 1e-3,
+        rng.standard_normal(5000) * 1e6,
+        np.array([1e18, -1e18, 3.5, 2.0 ** -70, 2.0 ** -64, 2.0 ** -63, 5e-324, -5e-324]),
+        np.array([0.1] * 777),
+        rng.standard_normal(4096) * np.exp(rng.uniform(-60, 40, 4096)),
+        np.array([]),
+    ]
+    for x in cases:
+        got, err = canonical_sum(x)
+        assert err == 0
+        assert got == _exact_sum_py(x)
+    _, err = canonical_sum(np.array([1.0, np.inf]))
+    assert err == 1
+    _, err = canonical_sum(np.array([2.0 ** 62]))
+    assert err == 1
+
+
+def _oracle_terms(wl, g, sum_mode, algo):
+    cfg = ob.default_config(sum_mode, algo)
+    ec = wl["ecount"][g, 0]
+    return ob.cost(wl["pos"][g, 0], wl["edges"][g, 0, :ec], wl["kind"][g], wl["value"][g], cfg)
+
+
+@pytest.mark.parametrize("n,layout,groups", [(1, "box", 1), (2, "box", 1), (20, "sphere", 1), (64, "box", 3),
+                                             (300, "box", 2), (1000, "sphere", 1), (2500, "box", 1)])
+def test_initial_cost_terms_bit_exact(gpu_lib, n, layout, groups):
+    wl = wlm.graph_workload("cost-terms", n, 3, groups, layout=layout)
+    with GraphEngine(n, wl["ecap"], 3, groups, seed="t") as eng:
+        eng.upload(wl["pos"], wl["edges"], wl["ecount"], wl["temperatures"], wl["kind"], wl["value"])
+        terms = eng.cost_terms()
+        cost = eng.download(positions=False, edges=False)["cost"]
+    for g in range(groups):
+        t = _oracle_terms(wl, g, ob.SUM_CANONICAL, ob.ALGO_OPTIMISED)
+        want = [t.conn, t.endpoint, t.edge, t.coll, t.dist, t.trans, t.total, float(t.reach0)]
+        for k in range(3):
+            assert list(terms[g, k]) == want
+            assert cost[g, k] == t.total
+        # reference-order sums (sequential fp64, fp32 centroid fold) agree to rounding
+        f = _oracle_terms(wl, g, ob.SUM_FSHARP, ob.ALGO_FAITHFUL if n <= 300 else ob.ALGO_OPTIMISED)
+        assert f.reach0 == t.reach0 and f.npairs == t.npairs
+        assert t.total == pytest.approx(f.total, rel=1e-9)
+        assert t.edge == pytest.approx(f.edge, rel=1e-12, abs=1e-12)
+        assert t.coll == pytest.approx(f.coll, rel=1e-12, abs=1e-12)
+        assert t.trans == pytest.approx(f.trans, rel=1e-12, abs=1e-12)
+        assert t.dist == pytest.approx(f.dist, rel=1e-5, abs=1e-9)   # fp32 centroid fold vs exact centroid
+
+
+def test_empty_graph_no_edges_and_dense_collisions(gpu_lib):
+    # config 1's start: unit sphere, Edges = [] (reference ProceduralGeneration.fs:42); and a
+    # collision-dense cloud where every node has many neighbours
+    n = 400
+    wl = wlm.graph_workload("dense", n, 2, 1, layout="sphere")
+    wl["ecount"][:] = 0
+    wl["pos"][:] *= 0.6
+    with GraphEngine(n, wl["ecap"], 2, 1, seed="t") as eng:
+        eng.upload(wl["pos"], wl["edges"], wl["ecount"], wl["temperatures"], wl["kind"], wl["value"])
+        terms = eng.cost_terms()
+    t = _oracle_terms(wl, 0, ob.SUM_CANONICAL, ob.ALGO_OPTIMISED)
+    assert t.npairs > 1000
+    assert list(terms[0, 0]) == [t.conn, t.endpoint, t.edge, t.coll, t.dist, t.trans, t.total, float(t.reach0)]
+    assert t.conn == (n - 1) * 1000.0 and t.endpoint == 10000.0
+
+
+def test_config1_trace_philox(gpu_lib):
+    """BASELINE config 1: 20 nodes, 5 temperatures 0.5-5.0, 1000 iterations, swap every 8,
+    sphere start without edges (reference ProceduralGeneration.fs:95-128)."""
+    n, T, iters, f = 20, 5, 1000, 8
+    wl = wlm.graph_workload("config1", n, T, 1, layout="sphere")
+    wl["ecount"][:] = 0
+    gpu = pu.gpu_run(wl, iters, f, seed="config1")
+    orc = pu.oracle_run(wl, iters, f, seed="config1")
+    pu.assert_same_run(wl, gpu, orc, iters)
+    tr = gpu["trace"]
+    assert set(np.unique(tr["kind"])) == {0, 1, 2}
+    assert (tr["flags"] & 4).any() and not (tr["flags"] & 4).all()
+    assert gpu["swap_trace"].any() and not gpu["swap_trace"].all()
+    assert gpu["stats"]["proposals"] == iters * T
+    assert gpu["stats"]["accepted"] == int(((tr["flags"] & 4) != 0).sum())
+    assert gpu["stats"]["swaps"] == int(gpu["swap_trace"].sum())
+    # the reference-order oracle (sequential sums, reference algorithms) makes the same decisions here
+    ref = pu.oracle_run(wl, iters, f, seed="config1", algo=ob.ALGO_FAITHFUL, sum_mode=ob.SUM_FSHARP)
+    same = np.array_equal(ref[0]["trace"]["flags"], orc[0]["trace"]["flags"]) and \
+        np.array_equal(ref[0]["swap_trace"], orc[0]["swap_trace"])
+    assert same, "canonical-sum and reference-order oracles diverged on config 1"
+    assert gpu["cost"][0] == pytest.approx(ref[0]["cost"], rel=1e-5)
+    assert np.allclose(gpu["pos"][0], ref[0]["pos"], rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize("n,T,G,iters,f,layout", [(50, 4, 3, 400, 5, "box"), (300, 6, 2, 300, 34, "box"),
+                                                   (1000, 16, 2, 130, 63, "box"), (200, 3, 1, 300, 7, "sphere")])
+def test_trace_parity_philox(gpu_lib, n, T, G, iters, f, layout):
+    wl = wlm.graph_workload("trace", n, T, G, layout=layout, index=n)
+    gpu = pu.gpu_run(wl, iters, f, seed=f"trace-{n}", chunks=[iters // 3, iters - iters // 3])
+    orc = pu.oracle_run(wl, iters, f, seed=f"trace-{n}")
+    pu.assert_same_run(wl, gpu, orc, iters)
+
+
+def test_trace_parity_injected_draws(gpu_lib):
+    n, T, G, iters, f = 120, 5, 2, 500, 6
+    wl = wlm.graph_workload("inject", n, T, G)
+    rng = np.random.default_rng(7)
+    passes = (iters + f - 1) // f
+    chain_u = rng.random((G, T, iters, nt.DRAWS_PER_STEP))
+    swap_u = rng.random((G, passes, T - 1))
+    # force the rare branches: exact 0.0 draws and draws just below 1
+    chain_u[0, 0, 3, :] = 0.0
+    chain_u[1, 2, 5, :] = np.nextafter(1.0, 0.0)
+    gpu = pu.gpu_run(wl, iters, f, chain_u=chain_u, swap_u=swap_u)
+    orc = pu.oracle_run(wl, iters, f, chain_u=chain_u, swap_u=swap_u)
+    pu.assert_same_run(wl, gpu, orc, iters)
+
+
+def test_perturb_only_and_custom_weights(gpu_lib):
+    n, T, iters, f = 150, 4, 300, 9
+    wl = wlm.graph_workload("perturb", n, T, 1)
+    w = [0.5, 2.0, 0.3, 1.5, 0.2, 0.7]
+    gpu = pu.gpu_run(wl, iters, f, seed="p", mutation_mode=nt.MUT_PERTURB_ONLY, weights=w)
+    orc = pu.oracle_run(wl, iters, f, seed="p", mutation_mode=ob.MUT_PERTURB_ONLY, weights=w)
+    pu.assert_same_run(wl, gpu, orc, iters)
+    assert (gpu["trace"]["kind"] == 0).all()
+
+
+def test_edge_capacity_hit_is_reported(gpu_lib):
+    n, T, iters, f = 30, 3, 300, 5
+    wl = wlm.graph_workload("cap", n, T, 1)
+    wl["temperatures"][:] = [[9.0, 7.0, 5.0]]           # hot: mostly topology moves
+    ecap = int(wl["ecount"].max()) + 2
+    wl["ecap"] = ecap
+    wl["edges"] = np.ascontiguousarray(wl["edges"][:, :, :ecap])
+    eng = GraphEngine(n, ecap, T, 1, swap_frequency=f, seed="cap")
+    eng.upload(wl["pos"], wl["edges"], wl["ecount"], wl["temperatures"], wl["kind"], wl["value"])
+    eng.enable_trace(iters, iters)
+    eng.run(iters)
+    tr, _ = eng.read_trace(iters, 0)
+    st = eng.stats()
+    res = eng.download()
+    eng.close()
+    orc = pu.oracle_run(wl, iters, f, seed="cap")
+    assert np.array_equal(tr["flags"], orc[0]["trace"]["flags"])
+    assert (tr["flags"] & 8).any()
+    assert st["status_bits"] == 1 << 5
+    assert np.array_equal(res["cost"][0], orc[0]["cost"])
+
+
+def test_10k_nodes_short_run_matches_oracle(gpu_lib):
+    """The headline shape (10k nodes, E = 15k) on 4 replicas for a few dozen steps."""
+    n, T, iters, f = 10000, 4, 24, 200
+    wl = wlm.graph_workload("c2-small", n, T, 1)
+    wl["temperatures"][:] = [[5.0, 2.5, 1.0, 0.5]]
+    gpu = pu.gpu_run(wl, iters, f, seed="c2")
+    orc = pu.oracle_run(wl, iters, f, seed="c2")
+    pu.assert_same_run(wl, gpu, orc, iters)
+
+
+def test_full_size_properties(gpu_lib):
+    """10k nodes x 64 replicas (BASELINE config 2): size-independent checks.  After a run the
+    tracked energy of every replica equals a from-scratch re-evaluation of its final state,
+    bit for bit; the slot map is a permutation; downloading and re-uploading reproduces the
+    same energies (idempotence)."""
+    n, T, iters = 10000, 64, 402
+    wl = wlm.graph_workload("c2", n, T, 1)
+    eng = GraphEngine(n, wl["ecap"], T, 1, seed="c2-full")
+    eng.upload(wl["pos"], wl["edges"], wl["ecount"], wl["temperatures"], wl["kind"], wl["value"])
+    eng.run(iters)
+    res = eng.download()
+    terms = eng.cost_terms()
+    st = eng.stats()
+    slots = eng.replica_slots()
+    assert st["status_bits"] == 0
+    assert st["proposals"] == iters * T and 0 < st["accepted"] < st["proposals"]
+    assert st["swap_attempts"] == 3 * (T - 1)
+    assert sorted(slots[0].tolist()) == list(range(T))
+    assert np.array_equal(terms[0, :, 6], res["cost"][0])
+    # spot-check three replicas against the oracle's cost of the downloaded state
+    cfg = ob.default_config(ob.SUM_CANONICAL, ob.ALGO_OPTIMISED)
+    for t in (0, 31, 63):
+        ec = res["ecount"][0, t]
+        o = ob.cost(res["pos"][0, t], res["edges"][0, t, :ec], wl["kind"][0], wl["value"][0], cfg)
+        assert o.total == res["cost"][0, t] and float(o.reach0) == terms[0, t, 7]
+    eng.upload(res["pos"], res["edges"], res["ecount"], wl["temperatures"], wl["kind"], wl["value"])
+    again = eng.download(positions=False, edges=False)["cost"]
+    eng.close()
+    assert np.array_equal(again, res["cost"])
