@@ -69,6 +69,15 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(f"{LIB_PATH} is missing: build it first (make -C procgen_amd/csrc)")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and a second
+    # runtime cannot open the GPU.  Importing torch first makes the loader satisfy this
+    # library's libamdhip64.so.7 dependency with the copy torch already mapped; without torch
+    # (e.g. under the F# host) the system ROCm runtime is used.
+    if os.environ.get("PROCGEN_PT_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     L.pt_last_error.restype = C.c_int

@@ -43,7 +43,7 @@ def path_plus_random_edges(n, n_edges, rng):
     duplicate in either direction (what Mutations.addEdge would accept,
     reference src/ParallelTempering.Core.fs:55).  Returned in LIST order
     (index 0 = list head); the order is a seeded shuffle."""
-    n_edges = max(n_edges, n - 1)
+    n_edges = min(max(n_edges, n - 1), n * (n - 1) // 2)
     seen = set()
     edges = []
     for i in range(n - 1):
