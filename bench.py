@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Benchmark of the parallel-tempering hot path on MI355X.
+
+Metric (BASELINE.json): Metropolis proposals/sec (whole node), 10k-node graph x 64 replicas.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" is one swap interval of the workload: f = swapFrequency(10000) = 200
+iterations of ParallelTempering.run's loop on every replica (propose + full
+weighted cost re-evaluation + Metropolis accept) followed by the sequential
+swap pass.  With N > 1 every rank (one process per GPU, launched by
+torch.distributed.run) runs its own 64-replica ladder -- independent chains
+shard across GPUs, so there is no data-path collective -- and the whole-job
+value is the sum over ranks divided by the slowest rank's time ("weak").
+All inputs are resident in HBM before the timed region.
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X FP32 vector spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nodes", type=int, default=10000)
+    ap.add_argument("--replicas", type=int, default=64)
+    ap.add_argument("--layout", default="box", choices=["box", "sphere"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(wl, f):
+    """Time the CPU oracle (a port of the reference's F# path; oracle/) on a bounded sample of
+    the same workload: the reference's own algorithms and summation order, one thread per
+    chain capped at the host's cores (reference src/Execution.fs:31-39)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    import parity_util as pu
+
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 16, wl["temps"])
+
+    def timed(algo, sum_mode, iters):
+        t0 = time.perf_counter()
+        pu.oracle_run(wl, iters, f, seed="bench-cpu", algo=algo, sum_mode=sum_mode, trace=False, threads=cores)
+        return time.perf_counter() - t0
+
+    out = {}
+    for name, algo, sum_mode in (("faithful", ob.ALGO_FAITHFUL, ob.SUM_FSHARP), ("optimised", ob.ALGO_OPTIMISED, ob.SUM_FSHARP)):
+        t_init = timed(algo, sum_mode, 0)               # initial costs only
+        iters, t = 1, timed(algo, sum_mode, 1)
+        budget = ARGS.cpu_seconds / 2.0
+        while t - t_init < budget / 4 and iters < 4096:  # grow the sample until it is long enough to time
+            iters *= 4
+            t = timed(algo, sum_mode, iters)
+        out[name] = dict(rate=wl["temps"] * iters / max(t - t_init, 1e-9), iters=iters, seconds=t - t_init)
+    return dict(value=out["faithful"]["rate"], unit="proposals/s", cores=cores, kind="port",
+                sample=f"{wl['temps']} replicas x {out['faithful']['iters']} iterations of the 10k-node workload, "
+                       f"reference algorithms (list-scan BFS, dictionary spatial hash), {out['faithful']['seconds']:.1f} s",
+                optimised_value=out["optimised"]["rate"],
+                optimised_sample=f"{wl['temps']} replicas x {out['optimised']['iters']} iterations, CSR BFS + grid hash, "
+                                 f"{out['optimised']['seconds']:.1f} s")
+
+
+def main():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.cuda.current_device()
+
+    from procgen_amd import workloads as wlm
+    from procgen_amd.engine import GraphEngine
+
+    n, R = ARGS.nodes, ARGS.replicas
+    wl = wlm.graph_workload("c2", n, R, 1, layout=ARGS.layout, index=rank)
+    eng = GraphEngine(n, wl["ecap"], R, 1, seed="procgen-bench/c2", device=dev, group_base=rank)
+    f = eng.swap_frequency
+    eng.upload(wl["pos"], wl["edges"], wl["ecount"], wl["temperatures"], wl["kind"], wl["value"])
+    eng.run(1)                                  # step 0 and its swap pass: intervals then start at 1, f+1, ...
+    for _ in range(ARGS.warmup):
+        eng.run(f)
+    eng.sync()
+    eng.kernel_time(reset=True)
+    st0 = eng.stats()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.sync()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(ARGS.steps):
+        eng.run(f)
+    eng.sync()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    kms, klaunch = eng.kernel_time()
+    st1 = eng.stats()
+    res = eng.download(positions=False, edges=True)
+    proposals_rank = st1["proposals"] - st0["proposals"]
+    assert proposals_rank == ARGS.steps * f * R, (proposals_rank, ARGS.steps * f * R)
+    assert st1["status_bits"] == 0, f"device status bits {st1['status_bits']:#x}"
+    total = proposals_rank * world
+    value = total / elapsed
+
+    if rank == 0:
+        e_mean = float(res["ecount"].mean())
+        bytes_per_prop = wlm.algorithmic_bytes_per_proposal(n, e_mean)
+        flops_per_prop = wlm.algorithmic_flops_per_proposal(n, e_mean)
+        props_per_launch = proposals_rank / max(klaunch, 1)
+        launch_s = (kms / max(klaunch, 1)) * 1e-3
+        achieved = bytes_per_prop * props_per_launch / launch_s / 1e9
+        valu = flops_per_prop * props_per_launch / launch_s / 1e12
+        line = {
+            "metric": "Metropolis proposals/sec (whole node), 10k-node graph x 64 replicas",
+            "value": value, "unit": "proposals/s", "n_gpus": world, "steps": ARGS.steps, "warmup": ARGS.warmup,
+            "ms_per_step": elapsed / ARGS.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 positions, f64 cost, i128 fixed-point sums", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {n}-node spatial graph x {R} replicas per GPU, E~1.5N, "
+                                   f"uniform-box layout, ladder 0.5-5.0, swap every {f}, full cost re-evaluation per proposal",
+                       "nodes": n, "replicas_per_gpu": R, "edges_mean": e_mean, "swap_frequency": f,
+                       "iterations_per_step": f, "accept_rate": (st1["accepted"] - st0["accepted"]) / max(proposals_rank, 1),
+                       "swap_rate": st1["swaps"] / max(st1["swap_attempts"], 1)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "pt_graph_steps_kernel", "kernel_ms_avg": kms / max(klaunch, 1), "launches": klaunch,
+                         "algorithmic_bytes_per_proposal": bytes_per_prop,
+                         "valu": {"achieved": valu, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": valu / FP32_VALU_PEAK_TFLOPS, "lane_ops_per_proposal": flops_per_prop}},
+        }
+        if not ARGS.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(wl, f)
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    ARGS = parse()
+    main()
