@@ -116,8 +116,12 @@ typedef struct pt_graph_config {
                                    (then group_count must be 1); 0 = temp_count */
     int32_t ladder_slot_base;   /* first temperature slot initially held by this engine's replicas */
     int32_t block_threads;      /* workgroup size, 0 = default */
-    int32_t reserved;
+    int32_t flags;              /* PT_FLAG_* */
 } pt_graph_config;
+
+/* Keep every array in global memory even when the replica would fit in LDS
+ * (same results; exists so tests can run both placements on one input). */
+#define PT_FLAG_GLOBAL_MEMORY_PLACEMENT 1
 
 /* Fill a config with the reference's defaults for N nodes, T temperatures. */
 void pt_graph_default_config(pt_graph_config *cfg, int32_t node_count, int32_t edge_capacity,

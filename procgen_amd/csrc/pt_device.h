@@ -169,3 +169,33 @@ __device__ inline int block_exclusive_scan(int *arr, int len, int *tmp)
     __syncthreads();
     return total;
 }
+
+// same over an unsigned short array (values and total must stay below 65536)
+__device__ inline int block_exclusive_scan_u16(unsigned short *arr, int len, int *tmp)
+{
+    const int B = blockDim.x, tid = threadIdx.x;
+    const int chunk = (len + B - 1) / B;
+    const int beg = min(tid * chunk, len), end = min(beg + chunk, len);
+    int s = 0;
+    for (int i = beg; i < end; i++) s += arr[i];
+    int lane = tid & (PT_WAVE - 1), wv = tid / PT_WAVE, nw = (B + PT_WAVE - 1) / PT_WAVE;
+    int inc = s;
+#pragma unroll
+    for (int off = 1; off < PT_WAVE; off <<= 1) {
+        int o = __shfl_up(inc, off, PT_WAVE);
+        if (lane >= off) inc += o;
+    }
+    if (lane == PT_WAVE - 1) tmp[wv] = inc;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int w = 0; w < nw; w++) { int t = tmp[w]; tmp[w] = run; run += t; }
+        tmp[16] = run;
+    }
+    __syncthreads();
+    int base = tmp[wv] + inc - s;
+    int total = tmp[16];
+    for (int i = beg; i < end; i++) { int t = arr[i]; arr[i] = (unsigned short)base; base += t; }
+    __syncthreads();
+    return total;
+}

@@ -33,12 +33,13 @@ struct pt_graph_engine {
     pt_graph_config cfg;
     int N = 0, Ecap = 0, T = 0, G = 0, R = 0, Tl = 0, f = 0;
     int device = 0, block = 0;
+    bool lds_mode = false;
     size_t lds_bytes = 0;
     hipStream_t stream = nullptr;
     GraphParams P;
     SwapParams SP;
-    DevBuf px, py, pz, ea, eb, ebuf, ecount, kind, value, origin, terminal, rowend, adj, cost, temps,
-        slot_of_rep, rep_of_slot, cells, sorted, queue, bitmap, chain_u, swap_u, trace, swap_trace,
+    DevBuf px, py, pz, ea, eb, et, ebuf, ecount, kind, value, origin, terminal, rowend, adj, cost, temps,
+        slot_of_rep, rep_of_slot, cells, sorted, queue, bitmap, collbuf, chain_u, swap_u, trace, swap_trace,
         stats, swap_stats, status, terms;
     long long step = 0;
     long long trace_steps = 0, trace_passes = 0;
@@ -65,6 +66,20 @@ struct DeviceGuard {
     explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
+
+// Smallest non-negative float s for which pred(s) holds; pred must be monotone (false ... true).
+// Positive floats order like their bit patterns, so this is a binary search over the bits.
+template <class Pred> float first_float_where(Pred pred)
+{
+    uint32_t lo = 0u, hi = 0x7f800000u;             // +0 .. +inf
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        float f; std::memcpy(&f, &mid, 4);
+        if (pred(f)) hi = mid; else lo = mid + 1;
+    }
+    float f; std::memcpy(&f, &lo, 4);
+    return f;
+}
 
 int drain_events(pt_graph_engine *e)
 {
@@ -95,9 +110,22 @@ int launch_steps(pt_graph_engine *e, long long step0, int nsteps)
         e->events_used++;
         PT_HIP_TRY(hipEventRecord(a, e->stream));
     }
-    hipLaunchKernelGGL(pt_graph_steps_kernel, dim3(e->R), dim3(e->block), e->lds_bytes, e->stream, e->P, step0, nsteps);
+    if (e->lds_mode)
+        hipLaunchKernelGGL(pt_graph_steps_kernel<true>, dim3(e->R), dim3(e->block), e->lds_bytes, e->stream, e->P, step0, nsteps);
+    else
+        hipLaunchKernelGGL(pt_graph_steps_kernel<false>, dim3(e->R), dim3(e->block), e->lds_bytes, e->stream, e->P, step0, nsteps);
     PT_HIP_TRY(hipGetLastError());
     if (e->timing) PT_HIP_TRY(hipEventRecord(b, e->stream));
+    return PT_OK;
+}
+
+int launch_init(pt_graph_engine *e, const GraphParams &P, int write_cost)
+{
+    if (e->lds_mode)
+        hipLaunchKernelGGL(pt_graph_init_kernel<true>, dim3(e->R), dim3(e->block), e->lds_bytes, e->stream, P, write_cost);
+    else
+        hipLaunchKernelGGL(pt_graph_init_kernel<false>, dim3(e->R), dim3(e->block), e->lds_bytes, e->stream, P, write_cost);
+    PT_HIP_TRY(hipGetLastError());
     return PT_OK;
 }
 
@@ -195,21 +223,42 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     block = std::min(1024, std::max(64, (block + 63) / 64 * 64));
     e->block = block;
 
-    // LDS: header, then the visited bitmap, then the bucket array when they fit
+    // Placement.  LDS-resident: positions (8N + 4N), u16 bucket table (2 M'), u16 sorted ids (2N)
+    // and the visited bitmap all in LDS; M' is the largest power of two <= M that fits.
     size_t lds = sizeof(Shared);
     int bitmap_in_lds = 0, cells_in_lds = 0;
-    size_t bm_bytes = (((size_t)nwords * 4 + 15) / 16) * 16;
-    if (lds + bm_bytes <= LDS_BUDGET) { bitmap_in_lds = 1; lds += bm_bytes; }
-    // several small replicas share a CU: keep each workgroup's LDS modest unless the graph is big
-    size_t cells_bytes = (M + 1) * 4;
-    size_t cells_cap = (block >= 1024) ? LDS_BUDGET : (LDS_BUDGET * block / 1024);
-    if (lds + cells_bytes <= cells_cap) { cells_in_lds = 1; lds += cells_bytes; }
+    int lgx = 0, lgy = 0, lgz = 0;
+    bool lds_mode = false;
+    if (!(cfg->flags & PT_FLAG_GLOBAL_MEMORY_PLACEMENT) && N < 65536) {
+        const size_t Npad = ((size_t)N + 3) & ~(size_t)3;
+        const size_t fixed = sizeof(Shared) + Npad * 14 + (((size_t)nwords * 4 + 15) / 16) * 16;
+        int lmb = mb;
+        while (lmb > 6 && fixed + ((size_t)2 << lmb) > LDS_BUDGET) lmb--;
+        // accept up to ~2.5 nodes per bucket; beyond that the global placement's bigger table wins
+        if (fixed + ((size_t)2 << lmb) <= LDS_BUDGET && ((size_t)1 << lmb) * 5 >= (size_t)N * 2) {
+            lds_mode = true;
+            lgx = (lmb + 2) / 3; lgy = (lmb - lgx + 1) / 2; lgz = lmb - lgx - lgy;
+            lds = fixed + ((size_t)2 << lmb);
+            bitmap_in_lds = 1;
+        }
+    }
+    if (!lds_mode) {
+        // header, then the visited bitmap, then the bucket array when they fit
+        size_t bm_bytes = (((size_t)nwords * 4 + 15) / 16) * 16;
+        if (lds + bm_bytes <= LDS_BUDGET) { bitmap_in_lds = 1; lds += bm_bytes; }
+        // several small replicas share a CU: keep each workgroup's LDS modest unless the graph is big
+        size_t cells_bytes = (M + 1) * 4;
+        size_t cells_cap = (block >= 1024) ? LDS_BUDGET : (LDS_BUDGET * block / 1024);
+        if (lds + cells_bytes <= cells_cap) { cells_in_lds = 1; lds += cells_bytes; }
+    }
     e->lds_bytes = lds;
+    e->lds_mode = lds_mode;
 
     hipError_t herr = hipSuccess;
     auto A = [&](DevBuf &b, size_t bytes) { if (herr == hipSuccess) herr = b.alloc(bytes); };
     A(e->px, sizeof(float) * R * N); A(e->py, sizeof(float) * R * N); A(e->pz, sizeof(float) * R * N);
     A(e->ea, sizeof(int) * (size_t)R * 2 * e->Ecap); A(e->eb, sizeof(int) * (size_t)R * 2 * e->Ecap);
+    A(e->et, sizeof(double) * (size_t)R * 2 * e->Ecap);
     A(e->ebuf, sizeof(int) * R); A(e->ecount, sizeof(int) * R);
     A(e->kind, (size_t)e->G * N); A(e->value, sizeof(double) * (size_t)e->G * N);
     A(e->origin, sizeof(int) * e->G); A(e->terminal, sizeof(int) * e->G);
@@ -217,19 +266,22 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     A(e->cost, sizeof(double) * R);
     A(e->temps, sizeof(double) * (size_t)e->G * Tl);
     A(e->slot_of_rep, sizeof(int) * (size_t)e->G * Tl); A(e->rep_of_slot, sizeof(int) * (size_t)e->G * Tl);
-    A(e->cells, cells_in_lds ? 16 : sizeof(int) * (size_t)R * (M + 1));
+    A(e->cells, (cells_in_lds || lds_mode) ? 16 : sizeof(int) * (size_t)R * (M + 1));
     A(e->sorted, sizeof(int) * (size_t)R * N);
     A(e->queue, sizeof(int) * (size_t)R * 2 * N);
     A(e->bitmap, bitmap_in_lds ? 16 : sizeof(unsigned) * (size_t)R * nwords);
+    const int collcap = 64;     // deferred collisions per thread; more are priced on the spot
+    A(e->collbuf, sizeof(float) * (size_t)R * collcap * 1024);
     A(e->stats, sizeof(unsigned long long) * (size_t)R * 4);
     A(e->swap_stats, sizeof(unsigned long long) * (size_t)e->G * 2);
     A(e->status, sizeof(unsigned));
     A(e->terms, sizeof(double) * (size_t)R * 8);
     if (herr == hipSuccess) herr = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (herr == hipSuccess && lds > 64 * 1024) {
-        herr = hipFuncSetAttribute((const void *)pt_graph_steps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (herr == hipSuccess)
-            herr = hipFuncSetAttribute((const void *)pt_graph_init_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const void *ks[2] = {lds_mode ? (const void *)pt_graph_steps_kernel<true> : (const void *)pt_graph_steps_kernel<false>,
+                             lds_mode ? (const void *)pt_graph_init_kernel<true> : (const void *)pt_graph_init_kernel<false>};
+        for (int i = 0; i < 2 && herr == hipSuccess; i++)
+            herr = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     if (herr != hipSuccess) {
         int code = herr == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP;
@@ -244,6 +296,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     P.N = N; P.Ecap = e->Ecap; P.T = e->T; P.G = e->G; P.Tl = Tl;
     P.slot_base = cfg->ladder_slot_base; P.group_base = cfg->group_base;
     P.mb = mb; P.gx = gx; P.gy = gy; P.gz = gz; P.nwords = nwords;
+    P.lgx = lgx; P.lgy = lgy; P.lgz = lgz;
     P.mutation_mode = cfg->mutation_mode; P.rng_mode = cfg->rng_mode;
     P.cells_in_lds = cells_in_lds; P.bitmap_in_lds = bitmap_in_lds;
     std::memcpy(P.w, cfg->weights, sizeof P.w);
@@ -251,15 +304,24 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     // cells a hair wider than min_distance: two points closer than min_distance are then always in
     // adjacent cells whatever the rounding of the coordinate scaling
     P.inv_cell = 1.0 / (cfg->min_distance * (1.0 + 0x1p-20));
+    {
+        int ex = 0;
+        const double mant = std::frexp(cfg->min_distance, &ex);
+        P.cell_pow2 = (mant == 0.5 && ex > -100 && ex < 100) ? 1 : 0;
+        P.inv_cell_f = P.cell_pow2 ? (float)(1.0 / cfg->min_distance) : 0.0f;
+        P.d2_hi = first_float_where([&](float s) { return (double)sqrtf(s) >= cfg->min_distance; });
+        P.d2_lo = first_float_where([&](float s) { return (double)sqrtf(s) > cfg->min_distance_eps; });
+        P.collcap = collcap;
+    }
     P.key0 = (uint32_t)key; P.key1 = (uint32_t)(key >> 32);
     P.px = e->px.as<float>(); P.py = e->py.as<float>(); P.pz = e->pz.as<float>();
-    P.ea = e->ea.as<int>(); P.eb = e->eb.as<int>(); P.ebuf = e->ebuf.as<int>(); P.ecount = e->ecount.as<int>();
+    P.ea = e->ea.as<int>(); P.eb = e->eb.as<int>(); P.et = e->et.as<double>(); P.ebuf = e->ebuf.as<int>(); P.ecount = e->ecount.as<int>();
     P.kind = e->kind.as<uint8_t>(); P.value = e->value.as<double>();
     P.origin_idx = e->origin.as<int>(); P.terminal_idx = e->terminal.as<int>();
     P.rowend = e->rowend.as<int>(); P.adj = e->adj.as<int>(); P.cost = e->cost.as<double>();
     P.temps = e->temps.as<double>(); P.slot_of_rep = e->slot_of_rep.as<int>();
     P.cells = e->cells.as<int>(); P.sorted = e->sorted.as<int>(); P.queue = e->queue.as<int>();
-    P.bitmap = e->bitmap.as<unsigned>();
+    P.bitmap = e->bitmap.as<unsigned>(); P.collbuf = e->collbuf.as<float>();
     P.stats = e->stats.as<unsigned long long>(); P.status = e->status.as<unsigned>();
     P.terms = nullptr;
 
@@ -352,9 +414,7 @@ int pt_graph_upload(pt_graph_engine *e, const float *positions, const int32_t *e
     (void)T;
 
     e->step = 0;
-    GraphParams P = e->P;
-    hipLaunchKernelGGL(pt_graph_init_kernel, dim3(R), dim3(e->block), e->lds_bytes, st, P, 1);
-    PT_HIP_TRY(hipGetLastError());
+    { int rc = launch_init(e, e->P, 1); if (rc) return rc; }
     PT_HIP_TRY(hipStreamSynchronize(st));
     e->uploaded = true;
     return PT_OK;
@@ -573,8 +633,7 @@ int pt_graph_cost_terms(pt_graph_engine *e, double *terms)
     DeviceGuard guard(e->device);
     GraphParams P = e->P;
     P.terms = e->terms.as<double>();
-    hipLaunchKernelGGL(pt_graph_init_kernel, dim3(e->R), dim3(e->block), e->lds_bytes, e->stream, P, 0);
-    PT_HIP_TRY(hipGetLastError());
+    { int rc = launch_init(e, P, 0); if (rc) return rc; }
     PT_HIP_TRY(hipStreamSynchronize(e->stream));
     std::vector<double> h((size_t)e->R * 8);
     std::vector<int> sor((size_t)e->G * e->Tl);
@@ -621,6 +680,20 @@ int pt_graph_kernel_time(pt_graph_engine *e, double *ms, int64_t *launches, int3
 }
 
 void *pt_graph_stream(pt_graph_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+#ifdef PT_STAMPS
+// diagnostic build only: read (and clear) the per-phase cycle totals, [4096][16]
+int pt_debug_read_stamps(unsigned long long *out, int clear)
+{
+    PT_HIP_TRY(hipDeviceSynchronize());
+    PT_HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 4096 * PT_NSTAMP));
+    if (clear) {
+        static std::vector<unsigned long long> z(4096 * PT_NSTAMP, 0ull);
+        PT_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z.data(), sizeof(unsigned long long) * z.size()));
+    }
+    return PT_OK;
+}
+#endif
 
 // unit-test hook: exact fx128 sum of n doubles on the device
 int pt_debug_canonical_sum(const double *terms, int64_t n, double *out, int32_t *range_error)

@@ -17,15 +17,19 @@ struct GraphParams {
     // sizes
     int N, Ecap, T, G, Tl, slot_base, group_base;
     int mb, gx, gy, gz;         // hash grid: M = 1<<mb buckets = (1<<gx)*(1<<gy)*(1<<gz)
+    int lgx, lgy, lgz;          // hash grid of the LDS-resident placement
     int nwords;                 // visited bitmap words
     int mutation_mode, rng_mode;
     int cells_in_lds, bitmap_in_lds;
     // cost
     double w[6], target_len, min_dist, eps, inv_cell;
+    float inv_cell_f, d2_hi, d2_lo;     // see cell_coord() and the collision test
+    int cell_pow2, collcap;
     uint32_t key0, key1;
     // state, replica-major
     float *px, *py, *pz;        // [R][N]
     int *ea, *eb;               // [R][2][Ecap]  ARRAY order (reverse of the reference's list order), double buffered
+    double *et;                 // [R][2][Ecap]  per-edge smoothTransitions term
     int *ebuf;                  // [R] which half is current
     int *ecount;                // [R]
     const uint8_t *kind;        // [G][N]
@@ -40,6 +44,7 @@ struct GraphParams {
     int *sorted;                // [R][N]
     int *queue;                 // [R][2][N]
     unsigned *bitmap;           // [R][nwords] (when not in LDS)
+    float *collbuf;             // [R][collcap][1024]
     // draws
     const double *chain_u;      // [G][Tl][draw_steps][6]
     long long draw_steps;

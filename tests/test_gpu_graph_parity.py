@@ -21,6 +21,9 @@ from procgen_amd.engine import GraphEngine, canonical_sum
 
 pytestmark = pytest.mark.gpu
 
+# both memory placements of the kernel must give the same bits
+PLACEMENTS = [pytest.param(0, id="lds"), pytest.param(nt.FLAG_GLOBAL_MEMORY_PLACEMENT, id="global")]
+
 
 def _exact_sum_py(x):
     tot = 0
@@ -57,11 +60,12 @@ def _oracle_terms(wl, g, sum_mode, algo):
     return ob.cost(wl["pos"][g, 0], wl["edges"][g, 0, :ec], wl["kind"][g], wl["value"][g], cfg)
 
 
+@pytest.mark.parametrize("flags", PLACEMENTS)
 @pytest.mark.parametrize("n,layout,groups", [(1, "box", 1), (2, "box", 1), (20, "sphere", 1), (64, "box", 3),
-                                             (300, "box", 2), (1000, "sphere", 1), (2500, "box", 1)])
-def test_initial_cost_terms_bit_exact(gpu_lib, n, layout, groups):
+                                             (300, "box", 2), (1000, "sphere", 1), (2500, "box", 1), (10000, "box", 1)])
+def test_initial_cost_terms_bit_exact(gpu_lib, n, layout, groups, flags):
     wl = wlm.graph_workload("cost-terms", n, 3, groups, layout=layout)
-    with GraphEngine(n, wl["ecap"], 3, groups, seed="t") as eng:
+    with GraphEngine(n, wl["ecap"], 3, groups, seed="t", flags=flags) as eng:
         eng.upload(wl["pos"], wl["edges"], wl["ecount"], wl["temperatures"], wl["kind"], wl["value"])
         terms = eng.cost_terms()
         cost = eng.download(positions=False, edges=False)["cost"]
@@ -81,14 +85,15 @@ def test_initial_cost_terms_bit_exact(gpu_lib, n, layout, groups):
         assert t.dist == pytest.approx(f.dist, rel=1e-5, abs=1e-9)   # fp32 centroid fold vs exact centroid
 
 
-def test_empty_graph_no_edges_and_dense_collisions(gpu_lib):
+@pytest.mark.parametrize("flags", PLACEMENTS)
+def test_empty_graph_no_edges_and_dense_collisions(gpu_lib, flags):
     # config 1's start: unit sphere, Edges = [] (reference ProceduralGeneration.fs:42); and a
     # collision-dense cloud where every node has many neighbours
     n = 400
     wl = wlm.graph_workload("dense", n, 2, 1, layout="sphere")
     wl["ecount"][:] = 0
     wl["pos"][:] *= 0.6
-    with GraphEngine(n, wl["ecap"], 2, 1, seed="t") as eng:
+    with GraphEngine(n, wl["ecap"], 2, 1, seed="t", flags=flags) as eng:
         eng.upload(wl["pos"], wl["edges"], wl["ecount"], wl["temperatures"], wl["kind"], wl["value"])
         terms = eng.cost_terms()
     t = _oracle_terms(wl, 0, ob.SUM_CANONICAL, ob.ALGO_OPTIMISED)
@@ -97,13 +102,14 @@ def test_empty_graph_no_edges_and_dense_collisions(gpu_lib):
     assert t.conn == (n - 1) * 1000.0 and t.endpoint == 10000.0
 
 
-def test_config1_trace_philox(gpu_lib):
+@pytest.mark.parametrize("flags", PLACEMENTS)
+def test_config1_trace_philox(gpu_lib, flags):
     """BASELINE config 1: 20 nodes, 5 temperatures 0.5-5.0, 1000 iterations, swap every 8,
     sphere start without edges (reference ProceduralGeneration.fs:95-128)."""
     n, T, iters, f = 20, 5, 1000, 8
     wl = wlm.graph_workload("config1", n, T, 1, layout="sphere")
     wl["ecount"][:] = 0
-    gpu = pu.gpu_run(wl, iters, f, seed="config1")
+    gpu = pu.gpu_run(wl, iters, f, seed="config1", flags=flags)
     orc = pu.oracle_run(wl, iters, f, seed="config1")
     pu.assert_same_run(wl, gpu, orc, iters)
     tr = gpu["trace"]
@@ -124,9 +130,10 @@ def test_config1_trace_philox(gpu_lib):
 
 @pytest.mark.parametrize("n,T,G,iters,f,layout", [(50, 4, 3, 400, 5, "box"), (300, 6, 2, 300, 34, "box"),
                                                    (1000, 16, 2, 130, 63, "box"), (200, 3, 1, 300, 7, "sphere")])
-def test_trace_parity_philox(gpu_lib, n, T, G, iters, f, layout):
+@pytest.mark.parametrize("flags", PLACEMENTS)
+def test_trace_parity_philox(gpu_lib, n, T, G, iters, f, layout, flags):
     wl = wlm.graph_workload("trace", n, T, G, layout=layout, index=n)
-    gpu = pu.gpu_run(wl, iters, f, seed=f"trace-{n}", chunks=[iters // 3, iters - iters // 3])
+    gpu = pu.gpu_run(wl, iters, f, seed=f"trace-{n}", chunks=[iters // 3, iters - iters // 3], flags=flags)
     orc = pu.oracle_run(wl, iters, f, seed=f"trace-{n}")
     pu.assert_same_run(wl, gpu, orc, iters)
 
@@ -178,12 +185,13 @@ def test_edge_capacity_hit_is_reported(gpu_lib):
     assert np.array_equal(res["cost"][0], orc[0]["cost"])
 
 
-def test_10k_nodes_short_run_matches_oracle(gpu_lib):
+@pytest.mark.parametrize("flags", PLACEMENTS)
+def test_10k_nodes_short_run_matches_oracle(gpu_lib, flags):
     """The headline shape (10k nodes, E = 15k) on 4 replicas for a few dozen steps."""
     n, T, iters, f = 10000, 4, 24, 200
     wl = wlm.graph_workload("c2-small", n, T, 1)
     wl["temperatures"][:] = [[5.0, 2.5, 1.0, 0.5]]
-    gpu = pu.gpu_run(wl, iters, f, seed="c2")
+    gpu = pu.gpu_run(wl, iters, f, seed="c2", flags=flags)
     orc = pu.oracle_run(wl, iters, f, seed="c2")
     pu.assert_same_run(wl, gpu, orc, iters)
 
