@@ -38,7 +38,7 @@ struct pt_graph_engine {
     hipStream_t stream = nullptr;
     GraphParams P;
     SwapParams SP;
-    DevBuf px, py, pz, ea, eb, et, ebuf, ecount, kind, value, origin, terminal, rowend, adj, cost, temps,
+    DevBuf px, py, pz, ea, eb, et, ebuf, ecount, kind, value, origin, terminal, rowend, adj, adj4, cost, temps,
         slot_of_rep, rep_of_slot, cells, sorted, queue, bitmap, collbuf, chain_u, swap_u, trace, swap_trace,
         stats, swap_stats, status, terms;
     long long step = 0;
@@ -263,6 +263,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     A(e->kind, (size_t)e->G * N); A(e->value, sizeof(double) * (size_t)e->G * N);
     A(e->origin, sizeof(int) * e->G); A(e->terminal, sizeof(int) * e->G);
     A(e->rowend, sizeof(int) * (size_t)R * N); A(e->adj, sizeof(int) * (size_t)R * e->Ecap);
+    A(e->adj4, sizeof(int4) * (size_t)R * N);
     A(e->cost, sizeof(double) * R);
     A(e->temps, sizeof(double) * (size_t)e->G * Tl);
     A(e->slot_of_rep, sizeof(int) * (size_t)e->G * Tl); A(e->rep_of_slot, sizeof(int) * (size_t)e->G * Tl);
@@ -318,7 +319,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     P.ea = e->ea.as<int>(); P.eb = e->eb.as<int>(); P.et = e->et.as<double>(); P.ebuf = e->ebuf.as<int>(); P.ecount = e->ecount.as<int>();
     P.kind = e->kind.as<uint8_t>(); P.value = e->value.as<double>();
     P.origin_idx = e->origin.as<int>(); P.terminal_idx = e->terminal.as<int>();
-    P.rowend = e->rowend.as<int>(); P.adj = e->adj.as<int>(); P.cost = e->cost.as<double>();
+    P.rowend = e->rowend.as<int>(); P.adj = e->adj.as<int>(); P.adj4 = e->adj4.as<int4>(); P.cost = e->cost.as<double>();
     P.temps = e->temps.as<double>(); P.slot_of_rep = e->slot_of_rep.as<int>();
     P.cells = e->cells.as<int>(); P.sorted = e->sorted.as<int>(); P.queue = e->queue.as<int>();
     P.bitmap = e->bitmap.as<unsigned>(); P.collbuf = e->collbuf.as<float>();

@@ -36,6 +36,7 @@ struct GraphParams {
     const double *value;        // [G][N]
     const int *origin_idx, *terminal_idx;   // [G]
     int *rowend, *adj;          // CSR of the current edges: row u = adj[rowend[u-1] .. rowend[u])
+    int4 *adj4;                 // [R][N] out-degree + first three out-neighbours of every node
     double *cost;               // [R]
     const double *temps;        // [G][Tl]
     const int *slot_of_rep;     // [G][Tl]
