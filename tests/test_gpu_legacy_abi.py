@@ -1,0 +1,117 @@
+"""The drop-in entry point the F# host binds (parallel_tempering_step), driven the way
+GPUTempering.optimize drives it (reference src/GPU.Wrappers.fs:271-344), against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import parity_util as pu
+from procgen_amd import native as nt
+from procgen_amd import workloads as wlm
+from procgen_amd.wrappers import Dispatch, DispatchThresholds, GPUTempering, SpatialGraph, Wrappers
+
+pytestmark = pytest.mark.gpu
+SEED = "libgpu_compute/parallel_tempering_step"
+
+
+def _job(n, T, name="legacy"):
+    wl = wlm.graph_workload(name, n, T, 1)
+    e = int(wl["ecount"][0, 0])
+    wl["value"][:] = 0.0                    # node values do not cross the legacy ABI
+    edges = [(int(a), int(b), 1.0) for a, b in wl["edges"][0, 0, :e]]
+    graphs = [SpatialGraph(list(range(n)), wl["pos"][0, t].copy(), list(edges)) for t in range(T)]
+    wl["ecap"] = e
+    wl["edges"] = np.ascontiguousarray(wl["edges"][:, :, :e])
+    return wl, graphs
+
+
+def _oracle(wl, iters, f):
+    return pu.oracle_run(wl, iters, f, seed=SEED, mutation_mode=ob.MUT_PERTURB_ONLY, trace=False)[0]
+
+
+def test_probe_then_available(gpu_lib):
+    gpu_lib.parallel_tempering_step(None, None, None, None, 0, 0, 0)
+    assert gpu_lib.pt_last_error() == 0
+    assert Wrappers.available() is True
+
+
+@pytest.mark.parametrize("n,T,iters", [(60, 4, 40), (250, 5, 70)])
+def test_step_per_iteration_matches_oracle(gpu_lib, n, T, iters):
+    gpu_lib.parallel_tempering_reset()
+    wl, graphs = _job(n, T)
+    temps = wl["temperatures"][0]
+    r = GPUTempering.optimize(temps, graphs, iters)
+    assert r[0] == "ok", r[1]
+    f = nt.swap_frequency(n)
+    o = _oracle(wl, iters, f)
+    got = np.stack([g.Positions for g in r[1]])
+    assert np.array_equal(got, o["pos"])
+    assert np.array_equal(GPUTempering.last_costs, o["cost"])
+    # one native call for the whole job gives the same bits
+    rb = GPUTempering.optimize_batched(temps, graphs, iters)
+    assert rb[0] == "ok"
+    assert np.array_equal(np.stack([g.Positions for g in rb[1]]), o["pos"])
+    assert np.array_equal(GPUTempering.last_costs, o["cost"])
+
+
+def test_f32_twin_and_state_reset(gpu_lib):
+    n, T, iters = 40, 3, 25
+    wl, graphs = _job(n, T, "legacy32")
+    e = int(wl["ecount"][0, 0])
+    pos = wl["pos"][0].astype(np.float32).reshape(-1).copy()
+    edges = wl["edges"][0, 0].reshape(-1).astype(np.int32).copy()
+    costs = np.zeros(T, np.float32)
+    temps = wl["temperatures"][0].astype(np.float32)
+    gpu_lib.parallel_tempering_reset()
+    for _ in range(iters):
+        gpu_lib.parallel_tempering_step_f32(nt.ptr(pos), nt.ptr(edges), nt.ptr(costs), nt.ptr(temps), n, e, T)
+        assert gpu_lib.pt_last_error() == 0
+    wl["temperatures"] = temps.astype(np.float64)[None]      # the ladder as the f32 caller sees it
+    o = _oracle(wl, iters, nt.swap_frequency(n))
+    assert np.array_equal(pos.reshape(T, n, 3), o["pos"])
+    assert np.array_equal(costs, o["cost"].astype(np.float32))
+    # a different shape restarts the call counter and the streams
+    gpu_lib.parallel_tempering_reset()
+    pos2 = wl["pos"][0].astype(np.float64).reshape(-1).copy()
+    c2 = np.zeros(T, np.float64); t2 = temps.astype(np.float64)
+    gpu_lib.parallel_tempering_step(nt.ptr(pos2), nt.ptr(edges), nt.ptr(c2), nt.ptr(t2), n, e, T)
+    o1 = _oracle(wl, 1, nt.swap_frequency(n))
+    assert np.array_equal(pos2.reshape(T, n, 3).astype(np.float32), o1["pos"])
+
+
+def test_bad_arguments_leave_outputs_untouched(gpu_lib):
+    pos = np.ones(9, np.float64); costs = np.full(1, -7.0); temps = np.array([1.0])
+    edges = np.array([0, 5], np.int32)                                   # index out of bounds
+    gpu_lib.parallel_tempering_reset()
+    gpu_lib.parallel_tempering_step(nt.ptr(pos), nt.ptr(edges), nt.ptr(costs), nt.ptr(temps), 3, 1, 1)
+    assert gpu_lib.pt_last_error() == 1 and costs[0] == -7.0 and np.all(pos == 1.0)
+    gpu_lib.parallel_tempering_step(nt.ptr(pos), None, nt.ptr(costs), nt.ptr(temps), -3, 0, 1)
+    assert gpu_lib.pt_last_error() == 1
+    temps[0] = -1.0
+    gpu_lib.parallel_tempering_step(nt.ptr(pos), None, nt.ptr(costs), nt.ptr(temps), 3, 0, 1)
+    assert gpu_lib.pt_last_error() == 1 and costs[0] == -7.0
+
+
+def test_wrapper_validation_on_device(gpu_lib):
+    # reference GPUIntegrationTests.fs:155-184
+    _, graphs = _job(10, 1, "val")
+    assert GPUTempering.optimize([-1.0], graphs, 100)[1].kind == "InvalidArgument"
+    assert GPUTempering.optimize([float("nan")], graphs, 100)[1].kind == "InvalidArgument"
+    assert GPUTempering.optimize([1.0], graphs, -1)[1].kind == "InvalidArgument"
+    assert GPUTempering.optimize([1.0], [], 10)[1].kind == "InvalidArgument"
+
+
+def test_dispatch_takes_the_gpu_path_above_thresholds(gpu_lib):
+    gpu_lib.parallel_tempering_reset()
+    n, T = 220, 3
+    wl, graphs = _job(n, T, "dispatch")
+    assert len(graphs[0].Edges) < Dispatch.getThresholds().EdgeCount
+    Dispatch.updateThresholds(DispatchThresholds(200, 300, 20))
+    try:
+        chains = Dispatch.optimize(wl["temperatures"][0], graphs, None, lambda g: 1.5, 20)
+    finally:
+        Dispatch.updateThresholds(DispatchThresholds())
+    assert len(chains) == T and all(c.Cost == 1.5 and c.AcceptanceRate == 0.5 for c in chains)
+    o = _oracle(wl, 20, nt.swap_frequency(n))
+    assert np.array_equal(np.stack([c.State.Positions for c in chains]), o["pos"])
