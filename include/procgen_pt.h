@@ -35,6 +35,7 @@ extern "C" {
 #define PT_ERR_CAPACITY          5   /* addEdge hit edge_capacity (treated as a no-op move) */
 #define PT_ERR_STREAM_EXHAUSTED  6   /* injected draw arrays shorter than the run */
 #define PT_ERR_OUT_OF_MEMORY     7
+#define PT_ERR_CLUSTER_TIMEOUT   8   /* workgroups cooperating on one replica lost each other (not co-resident) */
 
 /* Last error of the calling thread's most recent library call
  * (additive exports; the reference library reports nothing at all:
@@ -117,6 +118,8 @@ typedef struct pt_graph_config {
     int32_t ladder_slot_base;   /* first temperature slot initially held by this engine's replicas */
     int32_t block_threads;      /* workgroup size, 0 = default */
     int32_t flags;              /* PT_FLAG_* */
+    int32_t cluster_size;       /* workgroups (CUs) cooperating on one replica: 0 = choose, 1..4 */
+    int32_t reserved;
 } pt_graph_config;
 
 /* Keep every array in global memory even when the replica would fit in LDS

@@ -34,12 +34,13 @@ struct pt_graph_engine {
     int N = 0, Ecap = 0, T = 0, G = 0, R = 0, Tl = 0, f = 0;
     int device = 0, block = 0;
     bool lds_mode = false;
+    int C = 1;                  // workgroups per replica
     size_t lds_bytes = 0;
     hipStream_t stream = nullptr;
     GraphParams P;
     SwapParams SP;
     DevBuf px, py, pz, ea, eb, et, ebuf, ecount, kind, value, origin, terminal, rowend, adj, adj4, cost, temps,
-        slot_of_rep, rep_of_slot, cells, sorted, queue, bitmap, collbuf, chain_u, swap_u, trace, swap_trace,
+        slot_of_rep, rep_of_slot, cells, sorted, queue, bitmap, collbuf, comm, chain_u, swap_u, trace, swap_trace,
         stats, swap_stats, status, terms;
     long long step = 0;
     long long trace_steps = 0, trace_passes = 0;
@@ -110,7 +111,14 @@ int launch_steps(pt_graph_engine *e, long long step0, int nsteps)
         e->events_used++;
         PT_HIP_TRY(hipEventRecord(a, e->stream));
     }
-    if (e->lds_mode)
+    const dim3 cgrid((unsigned)((e->R + 7) / 8 * 8 * e->C));
+    if (e->C == 4)
+        hipLaunchKernelGGL(pt_graph_cluster_kernel<4>, cgrid, dim3(e->block), e->lds_bytes, e->stream, e->P, step0, nsteps);
+    else if (e->C == 3)
+        hipLaunchKernelGGL(pt_graph_cluster_kernel<3>, cgrid, dim3(e->block), e->lds_bytes, e->stream, e->P, step0, nsteps);
+    else if (e->C == 2)
+        hipLaunchKernelGGL(pt_graph_cluster_kernel<2>, cgrid, dim3(e->block), e->lds_bytes, e->stream, e->P, step0, nsteps);
+    else if (e->lds_mode)
         hipLaunchKernelGGL(pt_graph_steps_kernel<true>, dim3(e->R), dim3(e->block), e->lds_bytes, e->stream, e->P, step0, nsteps);
     else
         hipLaunchKernelGGL(pt_graph_steps_kernel<false>, dim3(e->R), dim3(e->block), e->lds_bytes, e->stream, e->P, step0, nsteps);
@@ -254,11 +262,54 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     e->lds_bytes = lds;
     e->lds_mode = lds_mode;
 
+    // Cluster size: as many workgroups per replica (up to 4) as keeps the whole grid co-resident at
+    // one workgroup per CU.  Only the LDS-resident placement has a cluster kernel.
+    int C = 1;
+    if (cfg->cluster_size < 0 || cfg->cluster_size > 4) { delete e; return pt::set_error(PT_ERR_INVALID_ARGUMENT, "cluster_size must be 0..4"); }
+    if (lds_mode && cfg->cluster_size != 1) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); prop.multiProcessorCount = 0; }
+        const long long slots = (long long)prop.multiProcessorCount * std::max<size_t>(1, LDS_BUDGET / std::max<size_t>(lds, 1));
+        const long long rows = ((long long)R + 7) / 8 * 8;
+        int want = cfg->cluster_size ? cfg->cluster_size : 4;
+        while (want > 1 && rows * want > slots) want--;
+        if (cfg->cluster_size > 1 && want != cfg->cluster_size) {
+            delete e;
+            return pt::set_error(PT_ERR_INVALID_ARGUMENT, "cluster_size needs more co-resident workgroups than the device has CUs");
+        }
+        C = want;
+        // census: shrink the cluster until a grid of that many workgroups (same LDS footprint) is
+        // observed to be resident all at once
+        while (C > 1) {
+            DevBuf probe;
+            unsigned init[2] = {0u, 1u}, res[2] = {0u, 0u};
+            if (probe.alloc(sizeof init) != hipSuccess) { (void)hipGetLastError(); C = 1; break; }
+            const unsigned blocks = (unsigned)(rows * C);
+            bool ok = hipMemcpy(probe.p, init, sizeof init, hipMemcpyHostToDevice) == hipSuccess;
+            if (ok && lds > 64 * 1024)
+                ok = hipFuncSetAttribute((const void *)pt_census_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+            if (ok) {
+                hipLaunchKernelGGL(pt_census_kernel, dim3(blocks), dim3(64), lds, 0, probe.as<unsigned>(), probe.as<unsigned>() + 1, blocks);
+                ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+                     hipMemcpy(res, probe.p, sizeof res, hipMemcpyDeviceToHost) == hipSuccess;
+            }
+            if (ok && res[0] == blocks && res[1] == 1u) break;
+            (void)hipGetLastError();
+            if (cfg->cluster_size > 1) {
+                delete e;
+                return pt::set_error(PT_ERR_INVALID_ARGUMENT, "cluster_size: that many workgroups are not co-resident on this device");
+            }
+            C--;
+        }
+    }
+    e->C = C;
+
     hipError_t herr = hipSuccess;
     auto A = [&](DevBuf &b, size_t bytes) { if (herr == hipSuccess) herr = b.alloc(bytes); };
     A(e->px, sizeof(float) * R * N); A(e->py, sizeof(float) * R * N); A(e->pz, sizeof(float) * R * N);
-    A(e->ea, sizeof(int) * (size_t)R * 2 * e->Ecap); A(e->eb, sizeof(int) * (size_t)R * 2 * e->Ecap);
-    A(e->et, sizeof(double) * (size_t)R * 2 * e->Ecap);
+    A(e->ea, sizeof(int) * (size_t)R * C * 2 * e->Ecap); A(e->eb, sizeof(int) * (size_t)R * C * 2 * e->Ecap);
+    A(e->et, sizeof(double) * (size_t)R * C * 2 * e->Ecap);
+    A(e->comm, sizeof(ClusterComm) * (size_t)R);
     A(e->ebuf, sizeof(int) * R); A(e->ecount, sizeof(int) * R);
     A(e->kind, (size_t)e->G * N); A(e->value, sizeof(double) * (size_t)e->G * N);
     A(e->origin, sizeof(int) * e->G); A(e->terminal, sizeof(int) * e->G);
@@ -272,16 +323,18 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     A(e->queue, sizeof(int) * (size_t)R * 2 * N);
     A(e->bitmap, bitmap_in_lds ? 16 : sizeof(unsigned) * (size_t)R * nwords);
     const int collcap = 64;     // deferred collisions per thread; more are priced on the spot
-    A(e->collbuf, sizeof(float) * (size_t)R * collcap * 1024);
+    A(e->collbuf, sizeof(float) * (size_t)R * C * collcap * 1024);
     A(e->stats, sizeof(unsigned long long) * (size_t)R * 4);
     A(e->swap_stats, sizeof(unsigned long long) * (size_t)e->G * 2);
     A(e->status, sizeof(unsigned));
     A(e->terms, sizeof(double) * (size_t)R * 8);
     if (herr == hipSuccess) herr = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (herr == hipSuccess && lds > 64 * 1024) {
-        const void *ks[2] = {lds_mode ? (const void *)pt_graph_steps_kernel<true> : (const void *)pt_graph_steps_kernel<false>,
-                             lds_mode ? (const void *)pt_graph_init_kernel<true> : (const void *)pt_graph_init_kernel<false>};
-        for (int i = 0; i < 2 && herr == hipSuccess; i++)
+        const void *ks[5] = {lds_mode ? (const void *)pt_graph_steps_kernel<true> : (const void *)pt_graph_steps_kernel<false>,
+                             lds_mode ? (const void *)pt_graph_init_kernel<true> : (const void *)pt_graph_init_kernel<false>,
+                             (const void *)pt_graph_cluster_kernel<2>, (const void *)pt_graph_cluster_kernel<3>,
+                             (const void *)pt_graph_cluster_kernel<4>};
+        for (int i = 0; i < (lds_mode ? 5 : 2) && herr == hipSuccess; i++)
             herr = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     if (herr != hipSuccess) {
@@ -296,6 +349,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     std::memset(&P, 0, sizeof P);
     P.N = N; P.Ecap = e->Ecap; P.T = e->T; P.G = e->G; P.Tl = Tl;
     P.slot_base = cfg->ladder_slot_base; P.group_base = cfg->group_base;
+    P.C = C;
     P.mb = mb; P.gx = gx; P.gy = gy; P.gz = gz; P.nwords = nwords;
     P.lgx = lgx; P.lgy = lgy; P.lgz = lgz;
     P.mutation_mode = cfg->mutation_mode; P.rng_mode = cfg->rng_mode;
@@ -316,7 +370,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     }
     P.key0 = (uint32_t)key; P.key1 = (uint32_t)(key >> 32);
     P.px = e->px.as<float>(); P.py = e->py.as<float>(); P.pz = e->pz.as<float>();
-    P.ea = e->ea.as<int>(); P.eb = e->eb.as<int>(); P.et = e->et.as<double>(); P.ebuf = e->ebuf.as<int>(); P.ecount = e->ecount.as<int>();
+    P.ea = e->ea.as<int>(); P.eb = e->eb.as<int>(); P.et = e->et.as<double>(); P.comm = e->comm.as<ClusterComm>(); P.ebuf = e->ebuf.as<int>(); P.ecount = e->ecount.as<int>();
     P.kind = e->kind.as<uint8_t>(); P.value = e->value.as<double>();
     P.origin_idx = e->origin.as<int>(); P.terminal_idx = e->terminal.as<int>();
     P.rowend = e->rowend.as<int>(); P.adj = e->adj.as<int>(); P.adj4 = e->adj4.as<int4>(); P.cost = e->cost.as<double>();
@@ -361,7 +415,8 @@ int pt_graph_upload(pt_graph_engine *e, const float *positions, const int32_t *e
 
     std::vector<float> sx((size_t)R * N), sy((size_t)R * N), sz((size_t)R * N);
     for (size_t i = 0; i < (size_t)R * N; i++) { sx[i] = positions[3 * i]; sy[i] = positions[3 * i + 1]; sz[i] = positions[3 * i + 2]; }
-    std::vector<int> ha((size_t)R * 2 * Ecap, 0), hb((size_t)R * 2 * Ecap, 0), hcount(R, 0), hbuf(R, 0);
+    const int C = e->C;
+    std::vector<int> ha((size_t)R * C * 2 * Ecap, 0), hb((size_t)R * C * 2 * Ecap, 0), hcount(R, 0), hbuf(R, 0);
     for (int r = 0; r < R; r++) {
         int ec = (edges && edge_counts) ? edge_counts[r] : 0;
         if (ec < 0 || ec > Ecap || ec > edge_stride) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "edge count exceeds edge_capacity or edge_stride");
@@ -370,9 +425,11 @@ int pt_graph_upload(pt_graph_engine *e, const float *positions, const int32_t *e
         for (int k = 0; k < ec; k++) {
             int a = src[2 * k], b = src[2 * k + 1];
             if (a < 0 || b < 0 || a >= N || b >= N) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "edge index out of bounds");  // reference GPU.Wrappers.fs:253-254
-            // list index k (0 = head) -> array index ec-1-k
-            ha[(size_t)r * 2 * Ecap + (ec - 1 - k)] = a;
-            hb[(size_t)r * 2 * Ecap + (ec - 1 - k)] = b;
+            // list index k (0 = head) -> array index ec-1-k, in every cluster member's copy
+            for (int c = 0; c < C; c++) {
+                ha[((size_t)r * C + c) * 2 * Ecap + (ec - 1 - k)] = a;
+                hb[((size_t)r * C + c) * 2 * Ecap + (ec - 1 - k)] = b;
+            }
         }
     }
     std::vector<uint8_t> hk((size_t)G * N);
@@ -412,6 +469,7 @@ int pt_graph_upload(pt_graph_engine *e, const float *positions, const int32_t *e
     PT_HIP_TRY(hipMemset(e->stats.p, 0, e->stats.bytes));
     PT_HIP_TRY(hipMemset(e->swap_stats.p, 0, e->swap_stats.bytes));
     PT_HIP_TRY(hipMemset(e->status.p, 0, sizeof(unsigned)));
+    PT_HIP_TRY(hipMemset(e->comm.p, 0, e->comm.bytes));
     (void)T;
 
     e->step = 0;
@@ -507,6 +565,9 @@ int pt_graph_set_step(pt_graph_engine *e, int64_t step)
     pt::clear_error();
     if (!e || step < 0) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null engine or negative step");
     std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    PT_HIP_TRY(hipStreamSynchronize(e->stream));
+    PT_HIP_TRY(hipMemset(e->comm.p, 0, e->comm.bytes));     // hand-off tags restart with the step counter
     e->step = step;
     return PT_OK;
 }
@@ -605,14 +666,15 @@ int pt_graph_download(pt_graph_engine *e, float *positions, int32_t *edges, int3
     if (edge_counts)
         for (int g = 0; g < G; g++) for (int t = 0; t < T; t++) edge_counts[output_row(e, sor, g, t)] = hcount[g * T + t];
     if (edges) {
-        std::vector<int> ha((size_t)R * 2 * Ecap), hb((size_t)R * 2 * Ecap), hbuf(R);
+        const int C = e->C;
+        std::vector<int> ha((size_t)R * C * 2 * Ecap), hb((size_t)R * C * 2 * Ecap), hbuf(R);
         PT_HIP_TRY(hipMemcpy(ha.data(), e->ea.p, sizeof(int) * ha.size(), hipMemcpyDeviceToHost));
         PT_HIP_TRY(hipMemcpy(hb.data(), e->eb.p, sizeof(int) * hb.size(), hipMemcpyDeviceToHost));
         PT_HIP_TRY(hipMemcpy(hbuf.data(), e->ebuf.p, sizeof(int) * R, hipMemcpyDeviceToHost));
         for (int g = 0; g < G; g++) for (int t = 0; t < T; t++) {
             int r = g * T + t, ec = hcount[r];
             if (ec > edge_stride) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "edge_stride smaller than a replica's edge count");
-            size_t src = ((size_t)r * 2 + hbuf[r]) * Ecap;
+            size_t src = (((size_t)r * C) * 2 + hbuf[r]) * Ecap;      // member 0's copy
             int32_t *dst = edges + (size_t)output_row(e, sor, g, t) * edge_stride * 2;
             for (int k = 0; k < ec; k++) { dst[2 * k] = ha[src + (ec - 1 - k)]; dst[2 * k + 1] = hb[src + (ec - 1 - k)]; }
         }

@@ -13,9 +13,22 @@
 #include "pt_device.h"
 #include "../../include/procgen_pt.h"
 
+// One record per cluster member (its own 128-byte line) and the leader's decision word.
+struct __align__(128) MemberSlot {
+    unsigned long long w[8];    // exact partial sums / BFS counts / error bit
+    unsigned long long flag;    // step + 1 once w[] is complete
+    unsigned long long pad[7];
+};
+struct __align__(128) ClusterComm {
+    MemberSlot m[4];
+    unsigned long long decision;    // (step + 1) << 8 | accept
+    unsigned long long pad[15];
+};
+
 struct GraphParams {
     // sizes
     int N, Ecap, T, G, Tl, slot_base, group_base;
+    int C;                      // workgroups per replica (cluster size); edge lists exist once per member
     int mb, gx, gy, gz;         // hash grid: M = 1<<mb buckets = (1<<gx)*(1<<gy)*(1<<gz)
     int lgx, lgy, lgz;          // hash grid of the LDS-resident placement
     int nwords;                 // visited bitmap words
@@ -28,8 +41,9 @@ struct GraphParams {
     uint32_t key0, key1;
     // state, replica-major
     float *px, *py, *pz;        // [R][N]
-    int *ea, *eb;               // [R][2][Ecap]  ARRAY order (reverse of the reference's list order), double buffered
-    double *et;                 // [R][2][Ecap]  per-edge smoothTransitions term
+    int *ea, *eb;               // [R][C][2][Ecap]  ARRAY order (reverse of the reference's list order), double buffered
+    double *et;                 // [R][C][2][Ecap]  per-edge smoothTransitions term
+    ClusterComm *comm;          // [R]
     int *ebuf;                  // [R] which half is current
     int *ecount;                // [R]
     const uint8_t *kind;        // [G][N]
@@ -45,7 +59,7 @@ struct GraphParams {
     int *sorted;                // [R][N]
     int *queue;                 // [R][2][N]
     unsigned *bitmap;           // [R][nwords] (when not in LDS)
-    float *collbuf;             // [R][collcap][1024]
+    float *collbuf;             // [R][C][collcap][1024]
     // draws
     const double *chain_u;      // [G][Tl][draw_steps][6]
     long long draw_steps;

@@ -14,7 +14,7 @@ class GraphEngine:
     def __init__(self, node_count, edge_capacity, temp_count, group_count=1, *, swap_frequency=0,
                  mutation_mode=nt.MUT_ADAPTIVE, rng_mode=nt.RNG_PHILOX, weights=None, seed=None,
                  philox_key=0, device=-1, group_base=0, ladder_temp_count=0, ladder_slot_base=0,
-                 block_threads=0, flags=0, target_edge_length=2.0, min_distance=0.5, min_distance_eps=0.001):
+                 block_threads=0, flags=0, cluster_size=0, target_edge_length=2.0, min_distance=0.5, min_distance_eps=0.001):
         self.L = nt.load()
         cfg = nt.GraphConfig()
         self.L.pt_graph_default_config(C.byref(cfg), node_count, edge_capacity, temp_count, group_count)
@@ -36,6 +36,7 @@ class GraphEngine:
         cfg.ladder_slot_base = ladder_slot_base
         cfg.block_threads = block_threads
         cfg.flags = flags
+        cfg.cluster_size = cluster_size
         self.cfg = cfg
         self.N, self.Ecap, self.T, self.G = node_count, max(edge_capacity, 1), temp_count, group_count
         self.Tl = ladder_temp_count or temp_count

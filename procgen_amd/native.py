@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PROCGEN_PT_LIB") or os.path.join(PKG_DIR, "lib", "lib
 
 PT_OK = 0
 ERR_NAMES = {1: "INVALID_ARGUMENT", 2: "NO_DEVICE", 3: "HIP", 4: "NUMERIC_RANGE", 5: "CAPACITY",
-             6: "STREAM_EXHAUSTED", 7: "OUT_OF_MEMORY"}
+             6: "STREAM_EXHAUSTED", 7: "OUT_OF_MEMORY", 8: "CLUSTER_TIMEOUT"}
 MUT_ADAPTIVE, MUT_PERTURB_ONLY = 0, 1
 RNG_PHILOX, RNG_INJECTED = 0, 1
 NODE_ORIGIN, NODE_TERMINAL, NODE_STANDARD = 0, 1, 2
@@ -36,7 +36,8 @@ class GraphConfig(C.Structure):
                 ("target_edge_length", C.c_double), ("min_distance", C.c_double),
                 ("min_distance_eps", C.c_double), ("philox_key", C.c_uint64), ("seed", C.c_char_p),
                 ("device", C.c_int32), ("group_base", C.c_int32), ("ladder_temp_count", C.c_int32),
-                ("ladder_slot_base", C.c_int32), ("block_threads", C.c_int32), ("flags", C.c_int32)]
+                ("ladder_slot_base", C.c_int32), ("block_threads", C.c_int32), ("flags", C.c_int32),
+                ("cluster_size", C.c_int32), ("reserved", C.c_int32)]
 
 
 class GraphStats(C.Structure):

@@ -28,11 +28,11 @@ def oracle_run(wl, iters, swap_freq, *, seed=None, key=None, mutation_mode=ob.MU
 
 
 def gpu_run(wl, iters, swap_freq, *, seed=None, key=0, mutation_mode=nt.MUT_ADAPTIVE, weights=None,
-            chain_u=None, swap_u=None, trace=True, block_threads=0, chunks=None, flags=0):
+            chain_u=None, swap_u=None, trace=True, block_threads=0, chunks=None, flags=0, cluster_size=0):
     eng = GraphEngine(wl["n"], wl["ecap"], wl["temps"], wl["groups"], swap_frequency=swap_freq,
                       mutation_mode=mutation_mode, weights=weights, seed=seed, philox_key=key,
                       rng_mode=nt.RNG_INJECTED if chain_u is not None else nt.RNG_PHILOX,
-                      block_threads=block_threads, flags=flags)
+                      block_threads=block_threads, flags=flags, cluster_size=cluster_size)
     try:
         eng.upload(wl["pos"], wl["edges"], wl["ecount"], wl["temperatures"], wl["kind"], wl["value"])
         init_cost = eng.download(positions=False, edges=False)["cost"]

@@ -23,6 +23,8 @@ pytestmark = pytest.mark.gpu
 
 # both memory placements of the kernel must give the same bits
 PLACEMENTS = [pytest.param(0, id="lds"), pytest.param(nt.FLAG_GLOBAL_MEMORY_PLACEMENT, id="global")]
+# ... and so must every number of workgroups cooperating on one replica
+CLUSTERS = [pytest.param(c, id=f"cluster{c}") for c in (1, 2, 3, 4)]
 
 
 def _exact_sum_py(x):
@@ -138,6 +140,15 @@ def test_trace_parity_philox(gpu_lib, n, T, G, iters, f, layout, flags):
     pu.assert_same_run(wl, gpu, orc, iters)
 
 
+@pytest.mark.parametrize("cluster", CLUSTERS)
+@pytest.mark.parametrize("n,T,G,iters,f", [(20, 5, 1, 300, 8), (300, 6, 2, 200, 34), (1000, 4, 2, 130, 63)])
+def test_trace_parity_clustered(gpu_lib, n, T, G, iters, f, cluster):
+    wl = wlm.graph_workload("cluster", n, T, G, index=n)
+    gpu = pu.gpu_run(wl, iters, f, seed=f"cl-{n}", chunks=[iters // 2, iters - iters // 2], cluster_size=cluster)
+    orc = pu.oracle_run(wl, iters, f, seed=f"cl-{n}")
+    pu.assert_same_run(wl, gpu, orc, iters)
+
+
 def test_trace_parity_injected_draws(gpu_lib):
     n, T, G, iters, f = 120, 5, 2, 500, 6
     wl = wlm.graph_workload("inject", n, T, G)
@@ -183,6 +194,16 @@ def test_edge_capacity_hit_is_reported(gpu_lib):
     assert (tr["flags"] & 8).any()
     assert st["status_bits"] == 1 << 5
     assert np.array_equal(res["cost"][0], orc[0]["cost"])
+
+
+@pytest.mark.parametrize("cluster", [2, 4])
+def test_10k_nodes_clustered_matches_oracle(gpu_lib, cluster):
+    n, T, iters, f = 10000, 4, 24, 200
+    wl = wlm.graph_workload("c2-small", n, T, 1)
+    wl["temperatures"][:] = [[5.0, 2.5, 1.0, 0.5]]
+    gpu = pu.gpu_run(wl, iters, f, seed="c2", cluster_size=cluster)
+    orc = pu.oracle_run(wl, iters, f, seed="c2")
+    pu.assert_same_run(wl, gpu, orc, iters)
 
 
 @pytest.mark.parametrize("flags", PLACEMENTS)
