@@ -125,6 +125,10 @@ typedef struct pt_graph_config {
 /* Keep every array in global memory even when the replica would fit in LDS
  * (same results; exists so tests can run both placements on one input). */
 #define PT_FLAG_GLOBAL_MEMORY_PLACEMENT 1
+/* Re-evaluate the full cost for every proposal (one workgroup, or a cluster of them, per replica)
+ * instead of updating the exact sums incrementally.  Same results bit for bit; a cluster_size
+ * above 1 implies it.  Incremental evaluation is the default whenever the replica fits in LDS. */
+#define PT_FLAG_FULL_EVALUATION 2
 
 /* Fill a config with the reference's defaults for N nodes, T temperatures. */
 void pt_graph_default_config(pt_graph_config *cfg, int32_t node_count, int32_t edge_capacity,
@@ -218,6 +222,18 @@ int pt_graph_get_stats(pt_graph_engine *e, pt_graph_stats *out);
  * events on the engine's stream since the last reset (for the benchmark). */
 int pt_graph_kernel_time(pt_graph_engine *e, double *ms, int64_t *launches, int32_t reset);
 void *pt_graph_stream(pt_graph_engine *e);
+
+/* How the engine decided to run (diagnostics, benchmark records). */
+typedef struct pt_graph_info_rec {
+    int32_t incremental;        /* 1: incremental evaluation, 0: full evaluation per proposal */
+    int32_t lds_placement;      /* 1: replica state resident in LDS */
+    int32_t cluster_size;       /* workgroups per replica */
+    int32_t block_threads;
+    int32_t lds_bytes;          /* dynamic LDS per workgroup of the step kernel */
+    int32_t swap_frequency;
+    int32_t reserved[2];
+} pt_graph_info_rec;
+int pt_graph_info(pt_graph_engine *e, pt_graph_info_rec *out);
 
 /* Unit-test hook: the exact fixed-point sum the engine uses, over n doubles. */
 int pt_debug_canonical_sum(const double *terms, int64_t n, double *out, int32_t *range_error);

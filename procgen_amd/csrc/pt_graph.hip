@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "pt_graph_kernels.hip.inc"
+#include "pt_graph_delta.hip.inc"
 
 namespace {
 
@@ -34,14 +35,15 @@ struct pt_graph_engine {
     int N = 0, Ecap = 0, T = 0, G = 0, R = 0, Tl = 0, f = 0;
     int device = 0, block = 0;
     bool lds_mode = false;
+    bool delta_mode = false;    // incremental evaluation (pt_graph_delta_kernel)
     int C = 1;                  // workgroups per replica
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0, delta_lds_bytes = 0;
     hipStream_t stream = nullptr;
     GraphParams P;
     SwapParams SP;
     DevBuf px, py, pz, ea, eb, et, ebuf, ecount, kind, value, origin, terminal, rowend, adj, adj4, cost, temps,
         slot_of_rep, rep_of_slot, cells, sorted, queue, bitmap, collbuf, comm, chain_u, swap_u, trace, swap_trace,
-        stats, swap_stats, status, terms;
+        stats, swap_stats, status, terms, dacc, dreach, dvis, dparent;
     long long step = 0;
     long long trace_steps = 0, trace_passes = 0;
     bool uploaded = false;
@@ -112,7 +114,9 @@ int launch_steps(pt_graph_engine *e, long long step0, int nsteps)
         PT_HIP_TRY(hipEventRecord(a, e->stream));
     }
     const dim3 cgrid((unsigned)((e->R + 7) / 8 * 8 * e->C));
-    if (e->C == 4)
+    if (e->delta_mode)
+        hipLaunchKernelGGL(pt_graph_delta_kernel, dim3(e->R), dim3(e->block), e->delta_lds_bytes, e->stream, e->P, step0, nsteps);
+    else if (e->C == 4)
         hipLaunchKernelGGL(pt_graph_cluster_kernel<4>, cgrid, dim3(e->block), e->lds_bytes, e->stream, e->P, step0, nsteps);
     else if (e->C == 3)
         hipLaunchKernelGGL(pt_graph_cluster_kernel<3>, cgrid, dim3(e->block), e->lds_bytes, e->stream, e->P, step0, nsteps);
@@ -262,11 +266,22 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     e->lds_bytes = lds;
     e->lds_mode = lds_mode;
 
+    // Incremental evaluation: the default whenever its LDS layout fits (positions, or the BFS's CSR
+    // that takes their place during a search, plus four visited sets) and no cluster was asked for.
+    size_t delta_region = 0;
+    if (!(cfg->flags & (PT_FLAG_GLOBAL_MEMORY_PLACEMENT | PT_FLAG_FULL_EVALUATION)) && N < 65535 && cfg->cluster_size <= 1) {
+        const size_t Npad = ((size_t)N + 3) & ~(size_t)3;
+        const size_t csr = (size_t)N * 4 + (((size_t)e->Ecap + 1) * 2 + 3) / 4 * 4 + (size_t)N * 2;
+        delta_region = (std::max(Npad * 12, csr) + 15) / 16 * 16;
+        const size_t need = sizeof(Shared) + delta_region + 4 * ((((size_t)nwords * 4 + 15) / 16) * 16);
+        if (need <= LDS_BUDGET) { e->delta_mode = true; e->delta_lds_bytes = need; }
+    }
+
     // Cluster size: as many workgroups per replica (up to 4) as keeps the whole grid co-resident at
     // one workgroup per CU.  Only the LDS-resident placement has a cluster kernel.
     int C = 1;
     if (cfg->cluster_size < 0 || cfg->cluster_size > 4) { delete e; return pt::set_error(PT_ERR_INVALID_ARGUMENT, "cluster_size must be 0..4"); }
-    if (lds_mode && cfg->cluster_size != 1) {
+    if (lds_mode && cfg->cluster_size != 1 && !e->delta_mode) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); prop.multiProcessorCount = 0; }
         const long long slots = (long long)prop.multiProcessorCount * std::max<size_t>(1, LDS_BUDGET / std::max<size_t>(lds, 1));
@@ -328,7 +343,15 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     A(e->swap_stats, sizeof(unsigned long long) * (size_t)e->G * 2);
     A(e->status, sizeof(unsigned));
     A(e->terms, sizeof(double) * (size_t)R * 8);
+    if (e->delta_mode) {
+        A(e->dacc, sizeof(fx128) * (size_t)R * ACC_COUNT);
+        A(e->dreach, sizeof(int) * (size_t)R * 4);
+        A(e->dvis, sizeof(unsigned) * (size_t)R * 2 * nwords);
+        A(e->dparent, sizeof(unsigned short) * (size_t)R * 4 * N);
+    }
     if (herr == hipSuccess) herr = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (herr == hipSuccess && e->delta_mode && e->delta_lds_bytes > 64 * 1024)
+        herr = hipFuncSetAttribute((const void *)pt_graph_delta_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->delta_lds_bytes);
     if (herr == hipSuccess && lds > 64 * 1024) {
         const void *ks[5] = {lds_mode ? (const void *)pt_graph_steps_kernel<true> : (const void *)pt_graph_steps_kernel<false>,
                              lds_mode ? (const void *)pt_graph_init_kernel<true> : (const void *)pt_graph_init_kernel<false>,
@@ -379,6 +402,10 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     P.bitmap = e->bitmap.as<unsigned>(); P.collbuf = e->collbuf.as<float>();
     P.stats = e->stats.as<unsigned long long>(); P.status = e->status.as<unsigned>();
     P.terms = nullptr;
+    if (e->delta_mode) {
+        P.dacc = e->dacc.as<fx128>(); P.dreach = e->dreach.as<int>(); P.dvis = e->dvis.as<unsigned>();
+        P.dparent = e->dparent.as<unsigned short>(); P.delta_region = (int)delta_region;
+    }
 
     SwapParams &S = e->SP;
     std::memset(&S, 0, sizeof S);
@@ -743,6 +770,20 @@ int pt_graph_kernel_time(pt_graph_engine *e, double *ms, int64_t *launches, int3
 }
 
 void *pt_graph_stream(pt_graph_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+int pt_graph_info(pt_graph_engine *e, pt_graph_info_rec *out)
+{
+    pt::clear_error();
+    if (!e || !out) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null argument");
+    std::memset(out, 0, sizeof *out);
+    out->incremental = e->delta_mode ? 1 : 0;
+    out->lds_placement = (e->delta_mode || e->lds_mode) ? 1 : 0;
+    out->cluster_size = e->C;
+    out->block_threads = e->block;
+    out->lds_bytes = (int32_t)(e->delta_mode ? e->delta_lds_bytes : e->lds_bytes);
+    out->swap_frequency = e->f;
+    return PT_OK;
+}
 
 #ifdef PT_STAMPS
 // diagnostic build only: read (and clear) the per-phase cycle totals, [4096][16]

@@ -69,6 +69,12 @@ struct GraphParams {
     unsigned long long *stats;  // [R][4] proposals, accepted, -, -
     unsigned *status;           // bitmask of PT_ERR_* seen
     double *terms;              // [R][8] or null
+    // state of the incremental evaluation (null when it is not available), kept between launches
+    fx128 *dacc;                // [R][8]  exact sums of the committed state, indexed like the LDS accumulators
+    int *dreach;                // [R][4]  reach from node 0, reach from the origin, current parent buffer of each
+    unsigned *dvis;             // [R][2][nwords]  visited sets of the two searches
+    unsigned short *dparent;    // [R][2][2][N]    per search, double buffered: discovery parent of every reached node
+    int delta_region;           // bytes of the LDS region shared by the positions and the BFS's adjacency
 };
 
 struct SwapParams {

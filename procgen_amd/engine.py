@@ -144,6 +144,12 @@ class GraphEngine:
         return dict(steps=s.steps, proposals=s.proposals, accepted=s.accepted,
                     swap_attempts=s.swap_attempts, swaps=s.swaps, status_bits=s.status_bits)
 
+    def info(self):
+        i = nt.GraphInfo()
+        nt.check(self.L.pt_graph_info(self.h, C.byref(i)))
+        return dict(incremental=bool(i.incremental), lds_placement=bool(i.lds_placement), cluster_size=i.cluster_size,
+                    block_threads=i.block_threads, lds_bytes=i.lds_bytes, swap_frequency=i.swap_frequency)
+
     def kernel_time(self, reset=False):
         ms, n = C.c_double(0), C.c_int64(0)
         nt.check(self.L.pt_graph_kernel_time(self.h, C.byref(ms), C.byref(n), int(reset)))

@@ -21,6 +21,7 @@ RNG_PHILOX, RNG_INJECTED = 0, 1
 NODE_ORIGIN, NODE_TERMINAL, NODE_STANDARD = 0, 1, 2
 DRAWS_PER_STEP = 6
 FLAG_GLOBAL_MEMORY_PLACEMENT = 1
+FLAG_FULL_EVALUATION = 2
 
 
 class PtError(RuntimeError):
@@ -58,9 +59,15 @@ EXPORTS = [
     "pt_graph_set_draws", "pt_graph_enable_trace", "pt_graph_read_trace", "pt_graph_run",
     "pt_graph_sync", "pt_graph_set_step", "pt_graph_run_to_swap_point", "pt_graph_local_energy_ptr",
     "pt_graph_swap_pass", "pt_graph_download", "pt_graph_replica_slots", "pt_graph_cost_terms",
-    "pt_graph_get_stats", "pt_graph_kernel_time", "pt_graph_stream", "pt_debug_canonical_sum",
+    "pt_graph_get_stats", "pt_graph_kernel_time", "pt_graph_stream", "pt_graph_info", "pt_debug_canonical_sum",
     "pt_geometric_ladder", "pt_swap_frequency", "pt_seed_key",
 ]
+
+class GraphInfo(C.Structure):
+    _fields_ = [("incremental", C.c_int32), ("lds_placement", C.c_int32), ("cluster_size", C.c_int32),
+                ("block_threads", C.c_int32), ("lds_bytes", C.c_int32), ("swap_frequency", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
+
 
 _lib = None
 

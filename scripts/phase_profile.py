@@ -16,7 +16,7 @@ from procgen_amd import workloads as wlm  # noqa: E402
 from procgen_amd.engine import GraphEngine  # noqa: E402
 
 NAMES = ["zero", "nodes+edges", "scan", "fill", "collide+dist1", "dist2", "bfs", "combine", "draw+decode", "accept",
-         "apply", "coll:loops", "coll:price", "coll:reduce", "-", "-"]
+         "apply", "coll:loops", "coll:price", "coll:reduce", "handoff wait", "-"]
 
 
 def main():
@@ -24,9 +24,10 @@ def main():
     R = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     iters = int(sys.argv[3]) if len(sys.argv) > 3 else 400
     block = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    cluster = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     L = nt.load()
     wl = wlm.graph_workload("c2", n, R, 1)
-    eng = GraphEngine(n, wl["ecap"], R, 1, seed="procgen-bench/c2", block_threads=block)
+    eng = GraphEngine(n, wl["ecap"], R, 1, seed="procgen-bench/c2", block_threads=block, cluster_size=cluster)
     eng.upload(wl["pos"], wl["edges"], wl["ecount"], wl["temperatures"], wl["kind"], wl["value"])
     eng.run(1 + eng.swap_frequency)
     eng.sync()
@@ -36,14 +37,23 @@ def main():
     eng.sync()
     ms, launches = eng.kernel_time()
     L.pt_debug_read_stamps(buf.ctypes.data_as(C.c_void_p), 1)
-    st = buf[:R].astype(np.float64)
-    tot = st.sum(axis=1)
-    print(f"n={n} replicas={R} iters={iters} kernel_ms={ms:.2f} us/proposal(wall)={ms * 1e3 / iters:.1f}")
-    print(f"cycles/proposal: mean {tot.mean() / iters:.0f} max {tot.max() / iters:.0f} (slowest replica {tot.argmax()})")
-    for k, name in enumerate(NAMES):
-        if st[:, k].sum() > 0:
-            print(f"  {name:14s} mean {st[:, k].mean() / iters:9.0f} cyc  {100 * st[:, k].sum() / tot.sum():5.1f}%   "
-                  f"hot(r0) {st[0, k] / iters:9.0f}  cold(r{R-1}) {st[R-1, k] / iters:9.0f}")
+    CS = cluster if cluster else 4
+    nblk = R if CS == 1 else (R + 7) // 8 * 8 * CS
+    st_all = buf[:nblk].astype(np.float64)
+    print(f"n={n} replicas={R} iters={iters} cluster={CS} kernel_ms={ms:.2f} us/proposal(wall)={ms * 1e3 / iters:.1f}")
+    roles = {"all": np.arange(nblk)} if CS == 1 else {
+        "leader(pair)": np.array([b for b in range(nblk) if (b >> 3) % CS == 0]),
+        "pair": np.array([b for b in range(nblk) if 0 < (b >> 3) % CS < CS - 1]),
+        "bfs+dist": np.array([b for b in range(nblk) if (b >> 3) % CS == CS - 1])}
+    for role, ids in roles.items():
+        if len(ids) == 0:
+            continue
+        st = st_all[ids]
+        tot = st.sum(axis=1)
+        print(f"[{role}] cycles/proposal: mean {tot.mean() / iters:.0f} max {tot.max() / iters:.0f}")
+        for k, name in enumerate(NAMES):
+            if st[:, k].sum() > 0:
+                print(f"  {name:14s} mean {st[:, k].mean() / iters:9.0f} cyc  {100 * st[:, k].sum() / tot.sum():5.1f}%")
     eng.close()
 
 

@@ -64,12 +64,17 @@ def assert_same_run(wl, gpu, orc, iters, *, trace=True):
         assert o["err"] == 0
         if trace:
             gt = gpu["trace"][:, g * T:(g + 1) * T]
+            first = None
             for f in TRACE_FIELDS:
                 if not np.array_equal(gt[f], o["trace"][f]):
                     bad = np.argwhere(gt[f] != o["trace"][f])[0]
-                    raise AssertionError(
-                        f"ladder {g}: trace field {f!r} first differs at step {bad[0]} chain {bad[1]}: "
-                        f"gpu {gt[bad[0], bad[1]]} oracle {o['trace'][bad[0], bad[1]]}")
+                    if first is None or (bad[0], bad[1]) < (first[0], first[1]):
+                        first = (bad[0], bad[1], f)
+            if first is not None:
+                s0, c0, f = first
+                raise AssertionError(
+                    f"ladder {g}: trace first differs at step {s0} chain {c0} (field {f!r}):\n"
+                    f"  fields {TRACE_FIELDS}\n  gpu    {gt[s0, c0]}\n  oracle {o['trace'][s0, c0]}")
             assert np.array_equal(gpu["swap_trace"][:, g, :], o["swap_trace"]), f"ladder {g}: swap decisions differ"
         assert np.array_equal(gpu["ecount"][g], o["ecount"]), f"ladder {g}: edge counts differ"
         assert np.array_equal(gpu["cost"][g], o["cost"]), f"ladder {g}: costs differ {gpu['cost'][g]} vs {o['cost']}"
@@ -77,4 +82,4 @@ def assert_same_run(wl, gpu, orc, iters, *, trace=True):
         for t in range(T):
             ec = o["ecount"][t]
             assert np.array_equal(gpu["edges"][g, t, :ec], o["edges"][t, :ec]), f"ladder {g} chain {t}: edge lists differ"
-    assert gpu["stats"]["status_bits"] == 0
+    assert gpu["stats"]["status_bits"] == 0, f"status bits {gpu['stats']['status_bits']:#x}"

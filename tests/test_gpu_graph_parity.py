@@ -21,9 +21,11 @@ from procgen_amd.engine import GraphEngine, canonical_sum
 
 pytestmark = pytest.mark.gpu
 
-# both memory placements of the kernel must give the same bits
-PLACEMENTS = [pytest.param(0, id="lds"), pytest.param(nt.FLAG_GLOBAL_MEMORY_PLACEMENT, id="global")]
-# ... and so must every number of workgroups cooperating on one replica
+# incremental evaluation (the default) and both memory placements of the full evaluation must
+# give the same bits
+PLACEMENTS = [pytest.param(0, id="incremental"), pytest.param(nt.FLAG_FULL_EVALUATION, id="full-lds"),
+              pytest.param(nt.FLAG_GLOBAL_MEMORY_PLACEMENT, id="full-global")]
+# ... and so must every number of workgroups cooperating on one replica's full evaluation
 CLUSTERS = [pytest.param(c, id=f"cluster{c}") for c in (1, 2, 3, 4)]
 
 
@@ -144,9 +146,67 @@ def test_trace_parity_philox(gpu_lib, n, T, G, iters, f, layout, flags):
 @pytest.mark.parametrize("n,T,G,iters,f", [(20, 5, 1, 300, 8), (300, 6, 2, 200, 34), (1000, 4, 2, 130, 63)])
 def test_trace_parity_clustered(gpu_lib, n, T, G, iters, f, cluster):
     wl = wlm.graph_workload("cluster", n, T, G, index=n)
-    gpu = pu.gpu_run(wl, iters, f, seed=f"cl-{n}", chunks=[iters // 2, iters - iters // 2], cluster_size=cluster)
+    gpu = pu.gpu_run(wl, iters, f, seed=f"cl-{n}", chunks=[iters // 2, iters - iters // 2], cluster_size=cluster,
+                     flags=nt.FLAG_FULL_EVALUATION)
     orc = pu.oracle_run(wl, iters, f, seed=f"cl-{n}")
     pu.assert_same_run(wl, gpu, orc, iters)
+
+
+def _topology_case(name):
+    """Inputs that make the reached set change: what the incremental evaluation must track."""
+    rng = np.random.default_rng(11)
+    if name == "near-tree":         # path + 6 extra edges: most removals cut a tree edge
+        n, T = 200, 4
+        wl = wlm.graph_workload("topo-tree", n, T, 1, avg_degree=2.06, edge_headroom=3.0)
+        temps = [8.0, 5.0, 3.0, 1.0]
+    elif name == "fragments":       # no spanning path: few nodes reached, additions extend the reach
+        n, T = 150, 4
+        wl = wlm.graph_workload("topo-frag", n, T, 1, edge_headroom=3.0)
+        e = rng.integers(0, n, size=(170, 2)).astype(np.int32)
+        e = e[e[:, 0] != e[:, 1]]
+        wl["edges"][:] = 0
+        wl["edges"][0, :, :len(e)] = e
+        wl["ecount"][:] = len(e)
+        temps = [9.0, 6.0, 2.5, 0.7]
+    elif name == "origin-elsewhere":    # the endpoint search starts at node 7, not node 0
+        n, T = 120, 3
+        wl = wlm.graph_workload("topo-origin", n, T, 1, avg_degree=2.2, edge_headroom=3.0)
+        wl["kind"][0, 0] = nt.NODE_STANDARD
+        wl["kind"][0, 7] = nt.NODE_ORIGIN
+        wl["kind"][0, n - 1] = nt.NODE_STANDARD
+        wl["kind"][0, 40] = nt.NODE_TERMINAL
+        temps = [7.0, 4.0, 1.5]
+    elif name == "duplicates":      # repeated and antiparallel edges in the uploaded list
+        n, T = 60, 3
+        wl = wlm.graph_workload("topo-dup", n, T, 1, avg_degree=2.4, edge_headroom=4.0)
+        ec = int(wl["ecount"][0, 0])
+        extra = np.concatenate([wl["edges"][0, 0, :6], wl["edges"][0, 0, 3:9, ::-1], wl["edges"][0, 0, :3]])
+        wl["edges"][0, :, ec:ec + len(extra)] = extra
+        wl["ecount"][:] = ec + len(extra)
+        temps = [8.0, 4.0, 2.5]
+    elif name == "dense":           # E > 3 N: the search's adjacency outgrows the position region
+        n, T = 64, 3
+        wl = wlm.graph_workload("topo-dense", n, T, 1, avg_degree=9.0, edge_headroom=2.0)
+        temps = [6.0, 3.0, 1.0]
+    else:
+        raise KeyError(name)
+    wl["temperatures"][:] = [temps]
+    return wl
+
+
+@pytest.mark.parametrize("flags", PLACEMENTS)
+@pytest.mark.parametrize("case", ["near-tree", "fragments", "origin-elsewhere", "duplicates", "dense"])
+def test_trace_parity_topology_cases(gpu_lib, case, flags):
+    wl = _topology_case(case)
+    iters, f = 600, 7
+    gpu = pu.gpu_run(wl, iters, f, seed=case, chunks=[250, 350], flags=flags)
+    orc = pu.oracle_run(wl, iters, f, seed=case)
+    pu.assert_same_run(wl, gpu, orc, iters)
+    reach = gpu["trace"]["reach0"]
+    if case in ("near-tree", "fragments"):
+        assert len(np.unique(reach)) > 3, "the case was meant to change the reached set"
+    # the tracked cost is a from-scratch evaluation of the final state
+    assert np.array_equal(gpu["terms"][0, :, 6], gpu["cost"][0])
 
 
 def test_trace_parity_injected_draws(gpu_lib):
@@ -201,7 +261,7 @@ def test_10k_nodes_clustered_matches_oracle(gpu_lib, cluster):
     n, T, iters, f = 10000, 4, 24, 200
     wl = wlm.graph_workload("c2-small", n, T, 1)
     wl["temperatures"][:] = [[5.0, 2.5, 1.0, 0.5]]
-    gpu = pu.gpu_run(wl, iters, f, seed="c2", cluster_size=cluster)
+    gpu = pu.gpu_run(wl, iters, f, seed="c2", cluster_size=cluster, flags=nt.FLAG_FULL_EVALUATION)
     orc = pu.oracle_run(wl, iters, f, seed="c2")
     pu.assert_same_run(wl, gpu, orc, iters)
 
@@ -225,6 +285,7 @@ def test_full_size_properties(gpu_lib):
     n, T, iters = 10000, 64, 402
     wl = wlm.graph_workload("c2", n, T, 1)
     eng = GraphEngine(n, wl["ecap"], T, 1, seed="c2-full")
+    assert eng.info()["incremental"]
     eng.upload(wl["pos"], wl["edges"], wl["ecount"], wl["temperatures"], wl["kind"], wl["value"])
     eng.run(iters)
     res = eng.download()
