@@ -38,20 +38,30 @@ __device__ __forceinline__ fx128 fx_neg(fx128 a)
 
 // trunc(|t| * 2^64) with the sign of t.  |t| must be < 2^62; otherwise (NaN and
 // infinities included) *err is set and the term counts as zero.
+// Below 2^32 (every term of a sane cost) the integer part and the fraction are split in fp64, both
+// exactly: trunc(|t|) fits 32 bits, |t| - trunc(|t|) is exact, and so is its product with 2^64.
 __device__ __forceinline__ fx128 fx_from_double(double t, unsigned &err)
 {
-    unsigned long long bits = (unsigned long long)__double_as_longlong(t);
-    int e = (int)((bits >> 52) & 0x7ffu);
-    unsigned long long m = bits & ((1ull << 52) - 1ull);
-    fx128 r = fx_zero();
-    if (e >= 1023 + 62) { err = 1u; return r; }
-    if (e == 0) e = 1; else m |= (1ull << 52);
-    int sh = e - 1011;              // value * 2^64 = m * 2^sh, sh in [-1010, 73]
-    if (sh >= 64) { r.hi = (long long)(m << (sh - 64)); }
-    else if (sh > 0) { r.lo = m << sh; r.hi = (long long)(m >> (64 - sh)); }
-    else if (sh == 0) { r.lo = m; }
-    else if (sh > -64) { r.lo = m >> (-sh); }
-    if (bits >> 63) r = fx_neg(r);
+    const double a = fabs(t);
+    fx128 r;
+    if (a < 4294967296.0) {
+        const double ti = trunc(a);
+        const double s = (a - ti) * 0x1p64;                         // < 2^64, exact
+        const unsigned h32 = __double2uint_rz(s * 0x1p-32);
+        const unsigned l32 = __double2uint_rz(fma((double)h32, -0x1p32, s));
+        r.lo = ((unsigned long long)h32 << 32) | (unsigned long long)l32;
+        r.hi = (long long)(unsigned long long)__double2uint_rz(ti);
+    } else {
+        unsigned long long bits = (unsigned long long)__double_as_longlong(t);
+        int e = (int)((bits >> 52) & 0x7ffu);
+        unsigned long long m = (bits & ((1ull << 52) - 1ull)) | (1ull << 52);
+        r = fx_zero();
+        if (e >= 1023 + 62) { err = 1u; return r; }
+        int sh = e - 1011;              // value * 2^64 = m * 2^sh, sh in [44, 73]
+        if (sh >= 64) r.hi = (long long)(m << (sh - 64));
+        else { r.lo = m << sh; r.hi = (long long)(m >> (64 - sh)); }
+    }
+    if (__double_as_longlong(t) < 0) r = fx_neg(r);
     return r;
 }
 
@@ -99,6 +109,7 @@ __device__ __forceinline__ void fx_atomic_add_lds(fx128 *acc, const fx128 &v)
 // every thread calls; lane 0 of each wave adds its wave's total into *acc
 __device__ __forceinline__ void fx_block_accumulate(fx128 *acc, fx128 v)
 {
+    if (__ballot((v.lo | (unsigned long long)v.hi) != 0ull) == 0ull) return;    // nothing in this wave
     v = fx_wave_reduce(v);
     if ((threadIdx.x & (PT_WAVE - 1)) == 0) fx_atomic_add_lds(acc, v);
 }

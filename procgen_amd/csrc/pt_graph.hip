@@ -43,7 +43,7 @@ struct pt_graph_engine {
     SwapParams SP;
     DevBuf px, py, pz, ea, eb, et, ebuf, ecount, kind, value, origin, terminal, rowend, adj, adj4, cost, temps,
         slot_of_rep, rep_of_slot, cells, sorted, queue, bitmap, collbuf, comm, chain_u, swap_u, trace, swap_trace,
-        stats, swap_stats, status, terms, dacc, dreach, dvis, dparent;
+        stats, swap_stats, status, terms, dacc, dreach, dvis, dparent, dparscr, epk;
     long long step = 0;
     long long trace_steps = 0, trace_passes = 0;
     bool uploaded = false;
@@ -266,14 +266,12 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     e->lds_bytes = lds;
     e->lds_mode = lds_mode;
 
-    // Incremental evaluation: the default whenever its LDS layout fits (positions, or the BFS's CSR
-    // that takes their place during a search, plus four visited sets) and no cluster was asked for.
-    size_t delta_region = 0;
-    if (!(cfg->flags & (PT_FLAG_GLOBAL_MEMORY_PLACEMENT | PT_FLAG_FULL_EVALUATION)) && N < 65535 && cfg->cluster_size <= 1) {
+    // Incremental evaluation: the default whenever its LDS layout fits (positions, parents, five
+    // visited sets), the edge list fits the workgroup's registers and no cluster was asked for.
+    if (!(cfg->flags & (PT_FLAG_GLOBAL_MEMORY_PLACEMENT | PT_FLAG_FULL_EVALUATION)) && N < 65535 && cfg->cluster_size <= 1 &&
+        (long long)e->Ecap <= (long long)DELTA_EPT * block) {
         const size_t Npad = ((size_t)N + 3) & ~(size_t)3;
-        const size_t csr = (size_t)N * 4 + (((size_t)e->Ecap + 1) * 2 + 3) / 4 * 4 + (size_t)N * 2;
-        delta_region = (std::max(Npad * 12, csr) + 15) / 16 * 16;
-        const size_t need = sizeof(Shared) + delta_region + 4 * ((((size_t)nwords * 4 + 15) / 16) * 16);
+        const size_t need = sizeof(Shared) + Npad * 12 + (((size_t)N * 2 + 15) / 16) * 16 + 5 * ((((size_t)nwords * 4 + 15) / 16) * 16);
         if (need <= LDS_BUDGET) { e->delta_mode = true; e->delta_lds_bytes = need; }
     }
 
@@ -347,7 +345,9 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         A(e->dacc, sizeof(fx128) * (size_t)R * ACC_COUNT);
         A(e->dreach, sizeof(int) * (size_t)R * 4);
         A(e->dvis, sizeof(unsigned) * (size_t)R * 2 * nwords);
-        A(e->dparent, sizeof(unsigned short) * (size_t)R * 4 * N);
+        A(e->dparent, sizeof(unsigned short) * (size_t)R * N);
+        A(e->dparscr, sizeof(unsigned short) * (size_t)R * N);
+        A(e->epk, sizeof(unsigned) * (size_t)R * DELTA_EPT * block);
     }
     if (herr == hipSuccess) herr = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (herr == hipSuccess && e->delta_mode && e->delta_lds_bytes > 64 * 1024)
@@ -404,7 +404,8 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     P.terms = nullptr;
     if (e->delta_mode) {
         P.dacc = e->dacc.as<fx128>(); P.dreach = e->dreach.as<int>(); P.dvis = e->dvis.as<unsigned>();
-        P.dparent = e->dparent.as<unsigned short>(); P.delta_region = (int)delta_region;
+        P.dparent = e->dparent.as<unsigned short>(); P.dparscr = e->dparscr.as<unsigned short>();
+        P.epk = e->epk.as<unsigned>(); P.epk_stride = DELTA_EPT * block;
     }
 
     SwapParams &S = e->SP;

@@ -71,10 +71,12 @@ struct GraphParams {
     double *terms;              // [R][8] or null
     // state of the incremental evaluation (null when it is not available), kept between launches
     fx128 *dacc;                // [R][8]  exact sums of the committed state, indexed like the LDS accumulators
-    int *dreach;                // [R][4]  reach from node 0, reach from the origin, current parent buffer of each
+    int *dreach;                // [R][4]  reach from node 0, reach from the origin, -, -
     unsigned *dvis;             // [R][2][nwords]  visited sets of the two searches
-    unsigned short *dparent;    // [R][2][2][N]    per search, double buffered: discovery parent of every reached node
-    int delta_region;           // bytes of the LDS region shared by the positions and the BFS's adjacency
+    unsigned short *dparent;    // [R][N]  search from node 0: the node every reached node was discovered from
+    unsigned short *dparscr;    // [R][N]  scratch: parents found while a proposal is evaluated
+    unsigned *epk;              // [R][epk_stride]  scratch: the edge list packed as a | b << 16
+    int epk_stride;             // edges-per-thread bound times the workgroup size
 };
 
 struct SwapParams {

@@ -17,6 +17,9 @@ from procgen_amd.engine import GraphEngine  # noqa: E402
 
 NAMES = ["zero", "nodes+edges", "scan", "fill", "collide+dist1", "dist2", "bfs", "combine", "draw+decode", "accept",
          "apply", "coll:loops", "coll:price", "coll:reduce", "handoff wait", "-"]
+# the incremental kernel stamps the same slots with its own phases
+NAMES_INC = ["centroid", "pairs+dist1+edges", "search:csr", "search:bfs", "search:restage", "dist2", "edge term", "-",
+             "decode", "decide", "apply", "edge loads issued", "draws", "draws barrier", "-", "(searches)"]
 
 
 def main():
@@ -27,7 +30,9 @@ def main():
     cluster = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     L = nt.load()
     wl = wlm.graph_workload("c2", n, R, 1)
-    eng = GraphEngine(n, wl["ecap"], R, 1, seed="procgen-bench/c2", block_threads=block, cluster_size=cluster)
+    flags = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    eng = GraphEngine(n, wl["ecap"], R, 1, seed="procgen-bench/c2", block_threads=block, cluster_size=cluster, flags=flags)
+    inc = eng.info()["incremental"]
     eng.upload(wl["pos"], wl["edges"], wl["ecount"], wl["temperatures"], wl["kind"], wl["value"])
     eng.run(1 + eng.swap_frequency)
     eng.sync()
@@ -37,7 +42,7 @@ def main():
     eng.sync()
     ms, launches = eng.kernel_time()
     L.pt_debug_read_stamps(buf.ctypes.data_as(C.c_void_p), 1)
-    CS = cluster if cluster else 4
+    CS = 1 if inc else (cluster if cluster else 4)
     nblk = R if CS == 1 else (R + 7) // 8 * 8 * CS
     st_all = buf[:nblk].astype(np.float64)
     print(f"n={n} replicas={R} iters={iters} cluster={CS} kernel_ms={ms:.2f} us/proposal(wall)={ms * 1e3 / iters:.1f}")
@@ -51,9 +56,13 @@ def main():
         st = st_all[ids]
         tot = st.sum(axis=1)
         print(f"[{role}] cycles/proposal: mean {tot.mean() / iters:.0f} max {tot.max() / iters:.0f}")
-        for k, name in enumerate(NAMES):
+        for k, name in enumerate(NAMES_INC if inc else NAMES):
             if st[:, k].sum() > 0:
-                print(f"  {name:14s} mean {st[:, k].mean() / iters:9.0f} cyc  {100 * st[:, k].sum() / tot.sum():5.1f}%")
+                if name.startswith("("):
+                    print(f"  {name:18s} per proposal: mean {st[:, k].mean() / iters:.4f} max {st[:, k].max() / iters:.4f}")
+                    continue
+                print(f"  {name:18s} mean {st[:, k].mean() / iters:9.0f} cyc  {100 * st[:, k].sum() / tot.sum():5.1f}%"
+                      f"   slowest replica {st[np.argmax(tot), k] / iters:9.0f}")
     eng.close()
 
 
