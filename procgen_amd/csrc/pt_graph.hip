@@ -43,7 +43,7 @@ struct pt_graph_engine {
     SwapParams SP;
     DevBuf px, py, pz, ea, eb, et, ebuf, ecount, kind, value, origin, terminal, rowend, adj, adj4, cost, temps,
         slot_of_rep, rep_of_slot, cells, sorted, queue, bitmap, collbuf, comm, chain_u, swap_u, trace, swap_trace,
-        stats, swap_stats, status, terms, dacc, dreach, dvis, dparent, dparscr, epk;
+        stats, swap_stats, status, terms, dacc, dreach, dvis, dparent, dparscr, dlabel, dlabscr, epk;
     long long step = 0;
     long long trace_steps = 0, trace_passes = 0;
     bool uploaded = false;
@@ -347,6 +347,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         A(e->dvis, sizeof(unsigned) * (size_t)R * 2 * nwords);
         A(e->dparent, sizeof(unsigned short) * (size_t)R * N);
         A(e->dparscr, sizeof(unsigned short) * (size_t)R * N);
+        A(e->dlabel, sizeof(unsigned) * (size_t)R * N); A(e->dlabscr, sizeof(unsigned) * (size_t)R * N);
         A(e->epk, sizeof(unsigned) * (size_t)R * DELTA_EPT * block);
     }
     if (herr == hipSuccess) herr = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
@@ -406,6 +407,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         P.dacc = e->dacc.as<fx128>(); P.dreach = e->dreach.as<int>(); P.dvis = e->dvis.as<unsigned>();
         P.dparent = e->dparent.as<unsigned short>(); P.dparscr = e->dparscr.as<unsigned short>();
         P.epk = e->epk.as<unsigned>(); P.epk_stride = DELTA_EPT * block;
+        P.dlabel = e->dlabel.as<unsigned>(); P.dlabscr = e->dlabscr.as<unsigned>();
     }
 
     SwapParams &S = e->SP;

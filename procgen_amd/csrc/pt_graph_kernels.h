@@ -71,10 +71,12 @@ struct GraphParams {
     double *terms;              // [R][8] or null
     // state of the incremental evaluation (null when it is not available), kept between launches
     fx128 *dacc;                // [R][8]  exact sums of the committed state, indexed like the LDS accumulators
-    int *dreach;                // [R][4]  reach from node 0, reach from the origin, -, -
+    int *dreach;                // [R][4]  reach from node 0, reach from the origin, largest discovery label in use, -
     unsigned *dvis;             // [R][2][nwords]  visited sets of the two searches
     unsigned short *dparent;    // [R][N]  search from node 0: the node every reached node was discovered from
     unsigned short *dparscr;    // [R][N]  scratch: parents found while a proposal is evaluated
+    unsigned *dlabel;           // [R][N]  discovery labels: strictly increasing from parent to child
+    unsigned *dlabscr;          // [R][N]  scratch: labels found while a proposal is evaluated
     unsigned *epk;              // [R][epk_stride]  scratch: the edge list packed as a | b << 16
     int epk_stride;             // edges-per-thread bound times the workgroup size
 };

@@ -18,8 +18,8 @@ from procgen_amd.engine import GraphEngine  # noqa: E402
 NAMES = ["zero", "nodes+edges", "scan", "fill", "collide+dist1", "dist2", "bfs", "combine", "draw+decode", "accept",
          "apply", "coll:loops", "coll:price", "coll:reduce", "handoff wait", "-"]
 # the incremental kernel stamps the same slots with its own phases
-NAMES_INC = ["centroid", "pairs+dist1+edges", "search:csr", "search:bfs", "search:restage", "dist2", "edge term", "-",
-             "decode", "decide", "apply", "edge loads issued", "draws", "draws barrier", "-", "(searches)"]
+NAMES_INC = ["centroid", "pairs+dist1+edges", "subtree:bitmap", "sweeps", "search 2 / end", "dist2", "edge term", "subtree:init",
+             "decode", "decide", "apply", "edge loads issued", "next draws", "subtree:rounds", "(rounds)", "(searches)"]
 
 
 def main():

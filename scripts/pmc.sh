@@ -12,7 +12,7 @@ import csv, collections, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for r in csv.DictReader(open(f)):
-    if "steps_kernel" in r["Kernel_Name"]:
+    if any(k in r["Kernel_Name"] for k in ("steps_kernel", "delta_kernel", "cluster_kernel")):
         agg[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
 last = sorted(agg, key=int)[-1]
 print("dispatch", last, {k: f"{v:.4g}" for k, v in agg[last].items()})
