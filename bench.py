@@ -7,8 +7,10 @@ Metric (BASELINE.json): Metropolis proposals/sec (whole node), 10k-node graph x 
 
 One "step" is one swap interval of the workload: f = swapFrequency(10000) = 200
 iterations of ParallelTempering.run's loop on every replica (propose + full
-weighted cost re-evaluation + Metropolis accept) followed by the sequential
-swap pass.  With N > 1 every rank (one process per GPU, launched by
+weighted cost + Metropolis accept) followed by the sequential swap pass.  The
+engine's default evaluation is incremental: the exact fixed-point cost sums are
+updated by the terms the move changes, which yields bit for bit the cost a full
+re-evaluation yields (--full-evaluation times the full re-evaluation kernels).  With N > 1 every rank (one process per GPU, launched by
 torch.distributed.run) runs its own 64-replica ladder -- independent chains
 shard across GPUs, so there is no data-path collective -- and the whole-job
 value is the sum over ranks divided by the slowest rank's time ("weak").
@@ -38,6 +40,8 @@ def parse():
     ap.add_argument("--replicas", type=int, default=64)
     ap.add_argument("--layout", default="box", choices=["box", "sphere"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-evaluation", action="store_true", help="re-evaluate the full cost per proposal")
+    ap.add_argument("--cluster", type=int, default=0, help="workgroups per replica of the full evaluation (0 = choose)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     return ap.parse_args()
 
@@ -74,6 +78,20 @@ def cpu_baseline(wl, f):
                                  f"{out['optimised']['seconds']:.1f} s")
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of the step kernel from the committed PMC passes (rocprofv3 cannot
+    run inside this process); None when no measurement of this kernel is on file."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)
+        if rec.get("kernel") == kernel:
+            return rec["hbm_bytes_per_launch"], rec.get("note", "")
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, "no PMC measurement of this kernel on file"
+
+
 def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,12 +107,15 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.cuda.current_device()
 
+    from procgen_amd import native as nt
     from procgen_amd import workloads as wlm
     from procgen_amd.engine import GraphEngine
 
     n, R = ARGS.nodes, ARGS.replicas
     wl = wlm.graph_workload("c2", n, R, 1, layout=ARGS.layout, index=rank)
-    eng = GraphEngine(n, wl["ecap"], R, 1, seed="procgen-bench/c2", device=dev, group_base=rank)
+    eng = GraphEngine(n, wl["ecap"], R, 1, seed="procgen-bench/c2", device=dev, group_base=rank,
+                      flags=nt.FLAG_FULL_EVALUATION if ARGS.full_evaluation else 0, cluster_size=ARGS.cluster)
+    info = eng.info()
     f = eng.swap_frequency
     eng.upload(wl["pos"], wl["edges"], wl["ecount"], wl["temperatures"], wl["kind"], wl["value"])
     eng.run(1)                                  # step 0 and its swap pass: intervals then start at 1, f+1, ...
@@ -141,20 +162,31 @@ def main():
         launch_s = (kms / max(klaunch, 1)) * 1e-3
         achieved = bytes_per_prop * props_per_launch / launch_s / 1e9
         valu = flops_per_prop * props_per_launch / launch_s / 1e12
+        if info["incremental"]:
+            kernel, how = "pt_graph_delta_kernel", "incremental exact cost update per proposal (same bits as a full re-evaluation)"
+        elif info["cluster_size"] > 1:
+            kernel, how = "pt_graph_cluster_kernel", f"full cost re-evaluation per proposal by {info['cluster_size']} workgroups per replica"
+        else:
+            kernel, how = "pt_graph_steps_kernel", "full cost re-evaluation per proposal"
+        traffic, traffic_note = measured_traffic(kernel)
         line = {
             "metric": "Metropolis proposals/sec (whole node), 10k-node graph x 64 replicas",
             "value": value, "unit": "proposals/s", "n_gpus": world, "steps": ARGS.steps, "warmup": ARGS.warmup,
             "ms_per_step": elapsed / ARGS.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 positions, f64 cost, i128 fixed-point sums", "data": "synthetic",
             "config": {"workload": f"configs[1]: {n}-node spatial graph x {R} replicas per GPU, E~1.5N, "
-                                   f"uniform-box layout, ladder 0.5-5.0, swap every {f}, full cost re-evaluation per proposal",
+                                   f"uniform-box layout, ladder 0.5-5.0, swap every {f}, {how}",
                        "nodes": n, "replicas_per_gpu": R, "edges_mean": e_mean, "swap_frequency": f,
                        "iterations_per_step": f, "accept_rate": (st1["accepted"] - st0["accepted"]) / max(proposals_rank, 1),
                        "swap_rate": st1["swaps"] / max(st1["swap_attempts"], 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "pt_graph_steps_kernel", "kernel_ms_avg": kms / max(klaunch, 1), "launches": klaunch,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         "kernel": kernel, "kernel_ms_avg": kms / max(klaunch, 1), "launches": klaunch,
+                         "proposals_per_launch": props_per_launch,
                          "algorithmic_bytes_per_proposal": bytes_per_prop,
+                         "algorithmic_note": "bytes and lane-ops one FULL cost evaluation touches (the reference's work per "
+                                             "proposal); the engine may do less work for the same result",
+                         "lds_bytes_per_workgroup": info["lds_bytes"], "block_threads": info["block_threads"],
                          "valu": {"achieved": valu, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": valu / FP32_VALU_PEAK_TFLOPS, "lane_ops_per_proposal": flops_per_prop}},
         }
