@@ -196,6 +196,9 @@ int pt_graph_set_step(pt_graph_engine *e, int64_t step);
 int pt_graph_run_to_swap_point(pt_graph_engine *e, int64_t max_steps, int64_t *steps_done, int32_t *swap_due);
 int pt_graph_local_energy_ptr(pt_graph_engine *e, double **d_energy_local, int32_t *count);
 int pt_graph_swap_pass(pt_graph_engine *e, const double *d_energy_all_replicas);
+/* Copy this engine's energies (replica order, temp_count * group_count doubles) to dst, a host or a
+ * device pointer; waits for the steps launched so far. */
+int pt_graph_read_energies(pt_graph_engine *e, double *dst);
 
 /* Download in SLOT order (chain i of ladder g = temperature slot i, as the
  * reference's chains array).  Any pointer may be NULL.  Synchronises.

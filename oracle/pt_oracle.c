@@ -703,13 +703,13 @@ int og_run(const og_run_args *a, const og_config *c)
     int64_t passes = 0;
     int threads = a->threads > 0 ? a->threads : 1;
     (void)threads;
-    for (int step = 0; step < a->iters; step++) {
-        for (int t = 0; t < T; t++) a->chain_streams[t].step_base = (int64_t)step * a->chain_streams[t].stride;
+    for (int64_t step = a->first_step; step < a->first_step + a->iters; step++) {
+        for (int t = 0; t < T; t++) a->chain_streams[t].step_base = step * a->chain_streams[t].stride;
 #ifdef _OPENMP
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1) if (threads > 1)
 #endif
         for (int t = 0; t < T; t++)
-            og_step(&ch[t], c, &a->chain_streams[t], a->trace ? &a->trace[(size_t)step * T + t] : NULL);
+            og_step(&ch[t], c, &a->chain_streams[t], a->trace ? &a->trace[(size_t)(step - a->first_step) * T + t] : NULL);
         if (a->swap_freq > 0 && step % a->swap_freq == 0) {
             for (int i = 0; i + 1 < T; i++) {
                 double p = og_swap_probability(ch[i].cost, ch[i].temperature, ch[i+1].cost, ch[i+1].temperature);

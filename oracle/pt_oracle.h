@@ -158,6 +158,7 @@ typedef struct og_run_args {
     og_trace_rec *trace;
     uint8_t *swap_trace;
     int64_t *n_swap_passes;     /* out, may be NULL */
+    int64_t first_step;         /* index of the first step: the steps run are first_step .. first_step+iters-1 */
 } og_run_args;
 
 int og_run(const og_run_args *a, const og_config *c);

@@ -629,6 +629,17 @@ int pt_graph_local_energy_ptr(pt_graph_engine *e, double **d_energy_local, int32
     return PT_OK;
 }
 
+int pt_graph_read_energies(pt_graph_engine *e, double *dst)
+{
+    pt::clear_error();
+    if (!e || !dst) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    PT_HIP_TRY(hipMemcpyAsync(dst, e->cost.p, sizeof(double) * (size_t)e->R, hipMemcpyDefault, e->stream));
+    PT_HIP_TRY(hipStreamSynchronize(e->stream));
+    return PT_OK;
+}
+
 int pt_graph_swap_pass(pt_graph_engine *e, const double *d_energy_all_replicas)
 {
     pt::clear_error();

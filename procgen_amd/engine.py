@@ -117,6 +117,10 @@ class GraphEngine:
         nt.check(self.L.pt_graph_local_energy_ptr(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def read_energies(self, dst_ptr):
+        """Copy the local energies (replica order) to a host or device address."""
+        nt.check(self.L.pt_graph_read_energies(self.h, C.c_void_p(dst_ptr)))
+
     def swap_pass(self, d_energy_all):
         nt.check(self.L.pt_graph_swap_pass(self.h, C.c_void_p(d_energy_all)))
 

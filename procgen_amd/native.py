@@ -58,7 +58,7 @@ EXPORTS = [
     "pt_graph_default_config", "pt_graph_create", "pt_graph_destroy", "pt_graph_upload",
     "pt_graph_set_draws", "pt_graph_enable_trace", "pt_graph_read_trace", "pt_graph_run",
     "pt_graph_sync", "pt_graph_set_step", "pt_graph_run_to_swap_point", "pt_graph_local_energy_ptr",
-    "pt_graph_swap_pass", "pt_graph_download", "pt_graph_replica_slots", "pt_graph_cost_terms",
+    "pt_graph_swap_pass", "pt_graph_read_energies", "pt_graph_download", "pt_graph_replica_slots", "pt_graph_cost_terms",
     "pt_graph_get_stats", "pt_graph_kernel_time", "pt_graph_stream", "pt_graph_info", "pt_debug_canonical_sum",
     "pt_geometric_ladder", "pt_swap_frequency", "pt_seed_key",
 ]

@@ -54,7 +54,8 @@ class RunArgs(C.Structure):
                 ("value", C.POINTER(C.c_double)), ("temperature", C.POINTER(C.c_double)),
                 ("cost", C.POINTER(C.c_double)), ("chain_streams", C.POINTER(Stream)),
                 ("swap_stream", C.POINTER(Stream)), ("trace", C.c_void_p),
-                ("swap_trace", C.POINTER(C.c_uint8)), ("n_swap_passes", C.POINTER(C.c_int64))]
+                ("swap_trace", C.POINTER(C.c_uint8)), ("n_swap_passes", C.POINTER(C.c_int64)),
+                ("first_step", C.c_int64)]
 
 
 SUM_FSHARP, SUM_CANONICAL = 0, 1
@@ -170,7 +171,8 @@ def philox_stream(key, stream_id, domain, count):
 
 
 def run(pos, edges, ecount, kind, value, temps, iters, swap_freq, cfg, *, key=None, stream_base=0,
-        swap_stream_id=0, chain_u=None, swap_u=None, trace=True, threads=1, stride=6):
+        swap_stream_id=0, chain_u=None, swap_u=None, trace=True, threads=1, stride=6, first_step=0,
+        stream_ids=None):
     """Run one ladder.  pos [T,N,3]; edges [T,ecap,2] (list order); ecount [T].
 
     Random draws come from Philox streams (key, stream ids stream_base+t, swap
@@ -199,7 +201,7 @@ def run(pos, edges, ecount, kind, value, temps, iters, swap_freq, cfg, *, key=No
         L.og_stream_array(C.byref(sw), _p(swap_u, C.c_double), swap_u.shape[0])
     else:
         for t in range(T):
-            L.og_stream_philox(C.byref(streams[t]), key, stream_base + t, 0)
+            L.og_stream_philox(C.byref(streams[t]), key, stream_ids[t] if stream_ids is not None else stream_base + t, 0)
         L.og_stream_philox(C.byref(sw), key, swap_stream_id, 1)
     for t in range(T):
         streams[t].stride = stride
@@ -210,7 +212,7 @@ def run(pos, edges, ecount, kind, value, temps, iters, swap_freq, cfg, *, key=No
     a = RunArgs(N, ecap, T, iters, swap_freq, threads, _p(pos, C.c_float), _p(edges, C.c_int32),
                 _p(ecount, C.c_int32), _p(kind, C.c_uint8), _p(value, C.c_double), _p(temps, C.c_double),
                 _p(costs, C.c_double), streams, C.pointer(sw),
-                tr.ctypes.data if trace else None, _p(st, C.c_uint8), C.pointer(npass))
+                tr.ctypes.data if trace else None, _p(st, C.c_uint8), C.pointer(npass), first_step)
     err = L.og_run(C.byref(a), C.byref(cfg))
     return dict(pos=pos, edges=edges, ecount=ecount, cost=costs, trace=tr,
                 swap_trace=st[:npass.value, :max(T - 1, 0)], err=err,
