@@ -84,16 +84,44 @@ __device__ __forceinline__ double fx_to_double(fx128 a)
     return neg ? -r : r;
 }
 
-__device__ __forceinline__ fx128 fx_wave_reduce(fx128 v)
+// Sum of a 32-bit value over the wavefront by data-parallel-primitive adds (no LDS traffic):
+// row shifts 1, 2, 3, then 4 and 8 build the inclusive prefix sum of every row of 16 lanes,
+// two row broadcasts carry the row totals on; lane 63 ends with the total of all 64 lanes.
+__device__ __forceinline__ unsigned wave_sum_u32_lane63(unsigned v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        fx128 o;
-        o.lo = __shfl_down(v.lo, off, PT_WAVE);
-        o.hi = __shfl_down(v.hi, off, PT_WAVE);
-        fx_add(v, o);
-    }
-    return v;
+    unsigned t = v;
+    t += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);      // row_shr:1
+    t += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);      // row_shr:2
+    t += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, true);      // row_shr:3
+    t += (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x114, 0xf, 0xe, true);      // row_shr:4, banks 1-3
+    t += (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x118, 0xf, 0xc, true);      // row_shr:8, banks 2-3
+    t += (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x142, 0xa, 0xf, true);      // row_bcast:15 into rows 1, 3
+    t += (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x143, 0xc, 0xf, true);      // row_bcast:31 into rows 2, 3
+    return t;
+}
+
+// Sum of v over the wavefront, valid in lane 63 only.  The 128 bits are cut into five limbs of
+// 26 bits; a limb summed over 64 lanes stays below 2^32, so the limbs add without carries and
+// are put together again (modulo 2^128: two's complement negatives come out right).
+__device__ __forceinline__ fx128 fx_wave_reduce_lane63(fx128 v)
+{
+    const unsigned long long hi = (unsigned long long)v.hi;
+    const unsigned m = (1u << 26) - 1u;
+    unsigned l0 = (unsigned)v.lo & m;
+    unsigned l1 = (unsigned)(v.lo >> 26) & m;
+    unsigned l2 = (unsigned)((v.lo >> 52) | (hi << 12)) & m;
+    unsigned l3 = (unsigned)(hi >> 14) & m;
+    unsigned l4 = (unsigned)(hi >> 40);
+    l0 = wave_sum_u32_lane63(l0); l1 = wave_sum_u32_lane63(l1); l2 = wave_sum_u32_lane63(l2);
+    l3 = wave_sum_u32_lane63(l3); l4 = wave_sum_u32_lane63(l4);
+    fx128 r;
+    r.lo = (unsigned long long)l0; r.hi = 0ll;
+    fx128 t;
+    t.lo = (unsigned long long)l1 << 26; t.hi = 0ll; fx_add(r, t);
+    t.lo = (unsigned long long)l2 << 52; t.hi = (long long)((unsigned long long)l2 >> 12); fx_add(r, t);
+    t.lo = 0ull; t.hi = (long long)((unsigned long long)l3 << 14); fx_add(r, t);
+    t.lo = 0ull; t.hi = (long long)((unsigned long long)l4 << 40); fx_add(r, t);
+    return r;
 }
 
 // Add v into a 128-bit accumulator in LDS with two 64-bit atomics; the carry of
@@ -106,12 +134,12 @@ __device__ __forceinline__ void fx_atomic_add_lds(fx128 *acc, const fx128 &v)
     atomicAdd((unsigned long long *)&acc->hi, (unsigned long long)v.hi + carry);
 }
 
-// every thread calls; lane 0 of each wave adds its wave's total into *acc
+// every thread calls; the last lane of each wave adds its wave's total into *acc
 __device__ __forceinline__ void fx_block_accumulate(fx128 *acc, fx128 v)
 {
     if (__ballot((v.lo | (unsigned long long)v.hi) != 0ull) == 0ull) return;    // nothing in this wave
-    v = fx_wave_reduce(v);
-    if ((threadIdx.x & (PT_WAVE - 1)) == 0) fx_atomic_add_lds(acc, v);
+    v = fx_wave_reduce_lane63(v);
+    if ((threadIdx.x & (PT_WAVE - 1)) == PT_WAVE - 1) fx_atomic_add_lds(acc, v);
 }
 
 // ---------------------------------------------------------------------------

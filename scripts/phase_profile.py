@@ -19,7 +19,7 @@ NAMES = ["zero", "nodes+edges", "scan", "fill", "collide+dist1", "dist2", "bfs",
          "apply", "coll:loops", "coll:price", "coll:reduce", "handoff wait", "-"]
 # the incremental kernel stamps the same slots with its own phases
 NAMES_INC = ["centroid", "pairs+dist1+edges", "subtree:bitmap", "sweeps", "search 2 / end", "dist2", "edge term", "subtree:init",
-             "decode", "decide", "apply", "edge loads issued", "next draws", "subtree:rounds", "(rounds)", "(searches)"]
+             "decode", "decide", "apply", "edge loads issued", "next draws", "subtree:rounds", "one stamp", "(searches)"]
 
 
 def main():
@@ -29,9 +29,11 @@ def main():
     block = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     cluster = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     L = nt.load()
+    ponly = int(os.environ.get("PERTURB_ONLY", "0"))
     wl = wlm.graph_workload("c2", n, R, 1)
     flags = int(sys.argv[6]) if len(sys.argv) > 6 else 0
-    eng = GraphEngine(n, wl["ecap"], R, 1, seed="procgen-bench/c2", block_threads=block, cluster_size=cluster, flags=flags)
+    eng = GraphEngine(n, wl["ecap"], R, 1, seed="procgen-bench/c2", block_threads=block, cluster_size=cluster, flags=flags,
+                      mutation_mode=nt.MUT_PERTURB_ONLY if ponly else nt.MUT_ADAPTIVE)
     inc = eng.info()["incremental"]
     eng.upload(wl["pos"], wl["edges"], wl["ecount"], wl["temperatures"], wl["kind"], wl["value"])
     eng.run(1 + eng.swap_frequency)
