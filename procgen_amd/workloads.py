@@ -104,6 +104,61 @@ def graph_workload(name, n, temps, groups=1, *, layout="box", avg_degree=3.0, ed
                 kind=kind, value=value, temperatures=temperatures, n_edges=n_edges)
 
 
+# ---- voxel chunks ---------------------------------------------------------------------------------
+MAT_AIR, MAT_STONE, MAT_SOIL, MAT_SAND, MAT_SNOW, MAT_ICE, MAT_GRASS, MAT_WATER = range(8)    # reference src/Voxel.Core.fs:79-87
+
+
+def determine_material(density, temperature, moisture, elevation):
+    """Material.determineMaterial (reference src/Voxel.Core.fs:225-235), vectorised."""
+    d, t, m, e = (np.asarray(a, np.float32) for a in (density, temperature, moisture, elevation))
+    out = np.where(m > np.float32(0.5), MAT_GRASS, MAT_SOIL)
+    out = np.where(e > np.float32(0.8), MAT_STONE, out)
+    out = np.where(e < np.float32(0.3), np.where(m > np.float32(0.6), MAT_SOIL, MAT_SAND), out)
+    out = np.where(t < np.float32(0.0), np.where(m > np.float32(0.7), MAT_ICE, MAT_SNOW), out)
+    out = np.where(d < np.float32(0.5), MAT_AIR, out)
+    return out.astype(np.uint8)
+
+
+def chunk_workload(name, chunks, temps=6, *, res=32, t_min=0.1, t_max=5.0, index=0, air_pockets=0.03):
+    """Synthetic voxel chunks: density 1 below a seeded value-noise height field and 0 above, a few
+    per cent of random air pockets below mid-height, moisture U(0,1), voxel temperature U(-10,30),
+    materials by determineMaterial.  Every replica of a chunk's ladder starts from the same chunk
+    (reference src/Terrain.Generation.fs:181-182); ladder = geometricLadder 0.1 5.0 6 (:18-23).
+    Arrays: density/moisture/temperature [chunks, temps, V], material [chunks, V]."""
+    V = res ** 3
+    dens = np.zeros((chunks, temps, V), np.float32)
+    moist = np.zeros((chunks, temps, V), np.float32)
+    temp = np.zeros((chunks, temps, V), np.float32)
+    mat = np.zeros((chunks, V), np.uint8)
+    v = np.arange(V)
+    x, y, z = v % res, (v // res) % res, v // (res * res)
+    for g in range(chunks):
+        rng = _rng("chunk-" + name, index * 1000003 + g)
+        coarse = rng.uniform(0.25 * res, 0.75 * res, size=(5, 5))
+        gx = x / (res - 1) * 4.0
+        gz = z / (res - 1) * 4.0
+        x0, z0 = np.minimum(gx.astype(int), 3), np.minimum(gz.astype(int), 3)
+        fx, fz = gx - x0, gz - z0
+        h = (coarse[x0, z0] * (1 - fx) * (1 - fz) + coarse[x0 + 1, z0] * fx * (1 - fz) +
+             coarse[x0, z0 + 1] * (1 - fx) * fz + coarse[x0 + 1, z0 + 1] * fx * fz)
+        d = (y < h).astype(np.float32)
+        pockets = (rng.random(V) < air_pockets) & (y <= res // 2)
+        d[pockets] = 0.0
+        m = rng.random(V).astype(np.float32)
+        t = rng.uniform(-10.0, 30.0, V).astype(np.float32)
+        dens[g, :], moist[g, :], temp[g, :] = d, m, t
+        mat[g] = determine_material(d, t, m, (y * np.float32(0.5)) / np.float32(100.0))
+    ladder = nt.geometric_ladder(t_min, t_max, temps)
+    return dict(chunks=chunks, temps=temps, res=res, V=V, density=dens, moisture=moist, temperature=temp, material=mat,
+                temperatures=np.tile(ladder, (chunks, 1)))
+
+
+def chunk_algorithmic_bytes_per_proposal(V):
+    """Bytes one full terrain-cost evaluation must touch: density and moisture f32, material u8,
+    visited bitmap read+write."""
+    return 9 * V + V / 4.0
+
+
 def algorithmic_bytes_per_proposal(n, e):
     """Bytes one full cost re-evaluation must touch: positions 12N, edge endpoints 8E,
     node values 4N, CSR 4(N+1)+4E, visited bitmap N/4 (read+write)."""
