@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full-evaluation", action="store_true", help="re-evaluate the full cost per proposal")
     ap.add_argument("--cluster", type=int, default=0, help="workgroups per replica of the full evaluation (0 = choose)")
+    ap.add_argument("--workload", default="graphs", choices=["graphs", "chunks"],
+                    help="graphs: BASELINE configs[1] (the headline); chunks: configs[2], 32^3 voxel chunks")
+    ap.add_argument("--chunks", type=int, default=4096, help="chunks per GPU of the chunk workload")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     return ap.parse_args()
 
@@ -90,6 +93,112 @@ def measured_traffic(kernel):
     except (OSError, ValueError, KeyError):
         pass
     return None, "no PMC measurement of this kernel on file"
+
+
+def chunk_cpu_baseline(wl, f):
+    """The terrain oracle (reference summation order) on one ladder for a few iterations."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    import terrain_binding as tb
+
+    cfg = tb.default_config(ob.SUM_FSHARP)
+    T = wl["temps"]
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 16, T)
+
+    def timed(iters):
+        t0 = time.perf_counter()
+        tb.run(wl["density"][0], wl["moisture"][0], wl["temperature"][0], wl["material"][0], wl["temperatures"][0],
+               iters, f, cfg, key=1, trace=False, threads=cores)
+        return time.perf_counter() - t0
+
+    t_init = timed(0)
+    iters, t = 8, timed(8)
+    while t - t_init < ARGS.cpu_seconds / 4 and iters < 65536:
+        iters *= 4
+        t = timed(iters)
+    return dict(value=T * iters / max(t - t_init, 1e-9), unit="proposals/s", cores=cores, kind="port",
+                sample=f"one chunk ladder ({T} temperatures) x {iters} iterations, full terrain cost per proposal, "
+                       f"{t - t_init:.1f} s")
+
+
+def main_chunks():
+    """BASELINE configs[2]: 32^3 voxel terrain chunks, 6 temperatures each, batched."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.cuda.current_device()
+    from procgen_amd import workloads as wlm
+    from procgen_amd.engine import ChunkEngine
+
+    G, T = ARGS.chunks, 6
+    distinct = min(G, 32)
+    wl = wlm.chunk_workload("c3", distinct, T, index=rank)
+    rep = (G + distinct - 1) // distinct
+    tile = lambda a: np.tile(a, (rep,) + (1,) * (a.ndim - 1))[:G]       # noqa: E731  (distinct chunks repeated; every ladder has its own draws)
+    eng = ChunkEngine(T, G, seed="procgen-bench/c3", device=dev, group_base=rank * G)
+    f = eng.swap_frequency
+    eng.upload(tile(wl["density"]), tile(wl["moisture"]), tile(wl["temperature"]), tile(wl["material"]), tile(wl["temperatures"]))
+    eng.run(1)
+    for _ in range(ARGS.warmup):
+        eng.run(f)
+    eng.sync()
+    eng.kernel_time(reset=True)
+    st0 = eng.stats()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(ARGS.steps):
+        eng.run(f)
+    eng.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kms, klaunch = eng.kernel_time()
+    st1 = eng.stats()
+    props = st1["proposals"] - st0["proposals"]
+    assert props == ARGS.steps * f * G * T and st1["status_bits"] == 0
+    if rank == 0:
+        V = wl["V"]
+        bpp = wlm.chunk_algorithmic_bytes_per_proposal(V)
+        per_launch = props / max(klaunch, 1)
+        launch_s = kms / max(klaunch, 1) * 1e-3
+        achieved = bpp * per_launch / launch_s / 1e9
+        line = {
+            "metric": "Metropolis proposals/sec (whole node), 32^3 voxel chunks x 6 temperatures", "value": props * world / elapsed,
+            "unit": "proposals/s", "n_gpus": world, "steps": ARGS.steps, "warmup": ARGS.warmup,
+            "ms_per_step": elapsed / ARGS.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 voxel fields, f64 cost, i128 fixed-point sums", "data": "synthetic",
+            "config": {"workload": f"configs[2]: {G} voxel chunks (32^3) x {T} temperatures per GPU, terrain constraints, "
+                                   f"ladder 0.1-5.0, swap every {f}, incremental exact cost update per proposal",
+                       "chunks_per_gpu": G, "temperatures": T, "swap_frequency": f,
+                       "accept_rate": (st1["accepted"] - st0["accepted"]) / max(props, 1)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "pt_chunk_steps_kernel", "kernel_ms_avg": kms / max(klaunch, 1),
+                         "launches": klaunch, "proposals_per_launch": per_launch, "algorithmic_bytes_per_proposal": bpp,
+                         "algorithmic_note": "bytes one FULL terrain-cost evaluation touches (the reference's work per proposal)"},
+        }
+        if not ARGS.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = chunk_cpu_baseline(wl, f)
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -201,4 +310,7 @@ def main():
 
 if __name__ == "__main__":
     ARGS = parse()
-    main()
+    if ARGS.workload == "chunks":
+        main_chunks()
+    else:
+        main()

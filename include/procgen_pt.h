@@ -238,6 +238,66 @@ typedef struct pt_graph_info_rec {
 } pt_graph_info_rec;
 int pt_graph_info(pt_graph_engine *e, pt_graph_info_rec *out);
 
+/* ======================================================================================
+ * Voxel-chunk engine: parallel tempering over 32^3 terrain chunks.
+ *
+ * Replaces, for whole batches of chunks, what the reference runs per chunk on the CPU:
+ * Terrain.Generation.generate (reference src/Terrain.Generation.fs:172-199) =
+ * ParallelTempering.run with mutateVoxels (:123-169) and the cost built by
+ * Terrain.Constraints.build (reference src/Terrain.Constraints.fs:213-247).
+ * group = one chunk's ladder; every temperature of a ladder holds its own copy of the chunk.
+ * Voxel v = x + 32 y + 1024 z (reference src/Voxel.Core.fs:113-114).
+ * Draw addresses of a step (8 per step): 0 voxel index, 1 refinement selector, 2 density single,
+ * 3 temperature selector, 4 temperature single, 5 moisture selector, 6 moisture single, 7 accept.
+ * ====================================================================================== */
+typedef struct pt_chunk_engine pt_chunk_engine;
+
+#define PT_CHUNK_RES 32
+#define PT_CHUNK_VOXELS (32 * 32 * 32)
+#define PT_CHUNK_DRAWS_PER_STEP 8
+#define PT_CHUNK_TERMS 12   /* traversability, geological, overhang, erosion, aesthetics, caves, performance,
+                               biomeTransition, total, cave reach, underground air voxels, solid voxels */
+
+typedef struct pt_chunk_config {
+    int32_t struct_size;
+    int32_t temp_count;             /* temperatures per chunk ladder (reference default 6) */
+    int32_t group_count;            /* chunks */
+    int32_t swap_frequency;         /* <= 0: 50 (reference src/Terrain.Generation.fs:18-23) */
+    int32_t rng_mode;               /* PT_RNG_PHILOX / PT_RNG_INJECTED */
+    int32_t device;                 /* -1: current */
+    int32_t group_base;             /* added to the ladder index in stream ids (distinct ranks, distinct streams) */
+    int32_t flags;
+    double weights[8];              /* traversability, geological, overhang, erosion, aesthetics, caves, performance, biomeTransition */
+    float density_mutation_scale;   /* 0.1 */
+    float solid_to_air_threshold;   /* 0.5 */
+    double refinement_probability;  /* 0.7 */
+    uint64_t philox_key;
+    const char *seed;               /* when not NULL: key = first 8 bytes of SHA-256(seed) */
+} pt_chunk_config;
+
+void pt_chunk_default_config(pt_chunk_config *cfg, int32_t temp_count, int32_t group_count);
+int pt_chunk_create(const pt_chunk_config *cfg, pt_chunk_engine **out);
+void pt_chunk_destroy(pt_chunk_engine *e);
+/* density, moisture, temperature [G][T][32768] f32; material [G][32768] u8 (shared by a ladder, never
+ * mutated); temperatures [G][T] fp64, index 0 hottest.  Computes the initial costs. */
+int pt_chunk_upload(pt_chunk_engine *e, const float *density, const float *moisture, const float *temperature,
+                    const uint8_t *material, const double *temperatures);
+/* injected draws: chain_u [G][T][steps][8], swap_u [G][passes][T-1] */
+int pt_chunk_set_draws(pt_chunk_engine *e, const double *chain_u, int64_t steps, const double *swap_u, int64_t passes);
+int pt_chunk_enable_trace(pt_chunk_engine *e, int64_t max_steps, int64_t max_passes);
+/* records as pt_trace_rec: kind 0 refinement / 1 flip, a = voxel, b = bit0 temperature mutated | bit1
+ * moisture mutated, reach0 = cave reach, reach_origin = underground air voxels (proposed state) */
+int pt_chunk_read_trace(pt_chunk_engine *e, pt_trace_rec *steps_out, int64_t n_steps, uint8_t *swaps_out, int64_t n_passes);
+int pt_chunk_run(pt_chunk_engine *e, int64_t steps);
+int pt_chunk_sync(pt_chunk_engine *e);
+/* slot order; any pointer may be NULL */
+int pt_chunk_download(pt_chunk_engine *e, float *density, float *moisture, float *temperature, double *costs);
+int pt_chunk_replica_slots(pt_chunk_engine *e, int32_t *slot_of_replica);
+/* from-scratch evaluation of the current states, slot order: terms [G][T][PT_CHUNK_TERMS] */
+int pt_chunk_cost_terms(pt_chunk_engine *e, double *terms);
+int pt_chunk_get_stats(pt_chunk_engine *e, pt_graph_stats *out);
+int pt_chunk_kernel_time(pt_chunk_engine *e, double *ms, int64_t *launches, int32_t reset);
+
 /* Unit-test hook: the exact fixed-point sum the engine uses, over n doubles. */
 int pt_debug_canonical_sum(const double *terms, int64_t n, double *out, int32_t *range_error);
 

@@ -834,3 +834,7 @@ int pt_debug_canonical_sum(const double *terms, int64_t n, double *out, int32_t 
 }
 
 }  // extern "C"
+
+// ---- voxel-chunk engine (same translation unit: it shares the swap kernel and the host helpers) ----
+#include "pt_chunk_kernels.hip.inc"
+#include "pt_chunk_host.hip.inc"

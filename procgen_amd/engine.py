@@ -160,6 +160,109 @@ class GraphEngine:
         return ms.value, n.value
 
 
+class ChunkEngine:
+    """Batched parallel tempering over 32^3 voxel chunks (pt_chunk_* of the C ABI): `group_count` chunks,
+    each with a ladder of `temp_count` temperatures."""
+
+    def __init__(self, temp_count, group_count, *, swap_frequency=0, rng_mode=nt.RNG_PHILOX, weights=None, seed=None,
+                 philox_key=0, device=-1, group_base=0, density_mutation_scale=None, refinement_probability=None,
+                 solid_to_air_threshold=None):
+        self.L = nt.load()
+        cfg = nt.ChunkConfig()
+        self.L.pt_chunk_default_config(C.byref(cfg), temp_count, group_count)
+        cfg.swap_frequency = swap_frequency
+        cfg.rng_mode = rng_mode
+        cfg.device = device
+        cfg.group_base = group_base
+        cfg.philox_key = philox_key
+        if weights is not None:
+            for i, w in enumerate(weights):
+                cfg.weights[i] = w
+        if density_mutation_scale is not None:
+            cfg.density_mutation_scale = density_mutation_scale
+        if refinement_probability is not None:
+            cfg.refinement_probability = refinement_probability
+        if solid_to_air_threshold is not None:
+            cfg.solid_to_air_threshold = solid_to_air_threshold
+        self._seed = seed.encode("utf-8") if seed is not None else None
+        cfg.seed = self._seed
+        self.h = C.c_void_p()
+        nt.check(self.L.pt_chunk_create(C.byref(cfg), C.byref(self.h)))
+        self.T, self.G, self.R, self.V = temp_count, group_count, temp_count * group_count, nt.CHUNK_VOXELS
+        self.swap_frequency = swap_frequency if swap_frequency > 0 else 50
+
+    def close(self):
+        if self.h:
+            self.L.pt_chunk_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def upload(self, density, moisture, temperature, material, temperatures):
+        """density/moisture/temperature [G,T,V] f32; material [G,V] u8; temperatures [G,T]."""
+        d = np.ascontiguousarray(density, np.float32).reshape(self.R, self.V)
+        m = np.ascontiguousarray(moisture, np.float32).reshape(self.R, self.V)
+        t = np.ascontiguousarray(temperature, np.float32).reshape(self.R, self.V)
+        k = np.ascontiguousarray(material, np.uint8).reshape(self.G, self.V)
+        lad = np.ascontiguousarray(temperatures, np.float64).reshape(self.G, self.T)
+        nt.check(self.L.pt_chunk_upload(self.h, nt.ptr(d), nt.ptr(m), nt.ptr(t), nt.ptr(k), nt.ptr(lad)))
+
+    def set_draws(self, chain_u, swap_u):
+        cu = np.ascontiguousarray(chain_u, np.float64)
+        steps = cu.size // (self.R * nt.CHUNK_DRAWS_PER_STEP)
+        su = np.ascontiguousarray(swap_u, np.float64)
+        passes = su.size // (self.G * max(self.T - 1, 1)) if self.T > 1 else 0
+        nt.check(self.L.pt_chunk_set_draws(self.h, nt.ptr(cu), steps, nt.ptr(su), passes))
+
+    def enable_trace(self, max_steps, max_passes):
+        nt.check(self.L.pt_chunk_enable_trace(self.h, max_steps, max_passes))
+
+    def read_trace(self, n_steps, n_passes):
+        tr = np.zeros((n_steps, self.R), nt.TRACE_DTYPE)
+        sw = np.zeros((n_passes, self.G, max(self.T - 1, 0)), np.uint8)
+        nt.check(self.L.pt_chunk_read_trace(self.h, nt.ptr(tr), n_steps, nt.ptr(sw) if sw.size else None, n_passes))
+        return tr, sw
+
+    def run(self, steps):
+        nt.check(self.L.pt_chunk_run(self.h, steps))
+
+    def sync(self):
+        nt.check(self.L.pt_chunk_sync(self.h))
+
+    def download(self, fields=True, costs=True):
+        d = np.zeros((self.G, self.T, self.V), np.float32) if fields else None
+        m = np.zeros((self.G, self.T, self.V), np.float32) if fields else None
+        t = np.zeros((self.G, self.T, self.V), np.float32) if fields else None
+        c = np.zeros((self.G, self.T), np.float64) if costs else None
+        nt.check(self.L.pt_chunk_download(self.h, nt.ptr(d), nt.ptr(m), nt.ptr(t), nt.ptr(c)))
+        return dict(density=d, moisture=m, temperature=t, cost=c)
+
+    def replica_slots(self):
+        s = np.zeros((self.G, self.T), np.int32)
+        nt.check(self.L.pt_chunk_replica_slots(self.h, nt.ptr(s)))
+        return s
+
+    def cost_terms(self):
+        t = np.zeros((self.G, self.T, nt.CHUNK_TERMS), np.float64)
+        nt.check(self.L.pt_chunk_cost_terms(self.h, nt.ptr(t)))
+        return t
+
+    def stats(self):
+        s = nt.GraphStats()
+        nt.check(self.L.pt_chunk_get_stats(self.h, C.byref(s)))
+        return dict(steps=s.steps, proposals=s.proposals, accepted=s.accepted,
+                    swap_attempts=s.swap_attempts, swaps=s.swaps, status_bits=s.status_bits)
+
+    def kernel_time(self, reset=False):
+        ms, n = C.c_double(0), C.c_int64(0)
+        nt.check(self.L.pt_chunk_kernel_time(self.h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+
 def canonical_sum(terms):
     """Exact fixed-point sum on the device (unit-test hook)."""
     L = nt.load()

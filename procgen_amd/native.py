@@ -61,7 +61,23 @@ EXPORTS = [
     "pt_graph_swap_pass", "pt_graph_read_energies", "pt_graph_download", "pt_graph_replica_slots", "pt_graph_cost_terms",
     "pt_graph_get_stats", "pt_graph_kernel_time", "pt_graph_stream", "pt_graph_info", "pt_debug_canonical_sum",
     "pt_geometric_ladder", "pt_swap_frequency", "pt_seed_key",
+    "pt_chunk_default_config", "pt_chunk_create", "pt_chunk_destroy", "pt_chunk_upload", "pt_chunk_set_draws",
+    "pt_chunk_enable_trace", "pt_chunk_read_trace", "pt_chunk_run", "pt_chunk_sync", "pt_chunk_download",
+    "pt_chunk_replica_slots", "pt_chunk_cost_terms", "pt_chunk_get_stats", "pt_chunk_kernel_time",
 ]
+
+class ChunkConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("temp_count", C.c_int32), ("group_count", C.c_int32),
+                ("swap_frequency", C.c_int32), ("rng_mode", C.c_int32), ("device", C.c_int32), ("group_base", C.c_int32),
+                ("flags", C.c_int32), ("weights", C.c_double * 8), ("density_mutation_scale", C.c_float),
+                ("solid_to_air_threshold", C.c_float), ("refinement_probability", C.c_double),
+                ("philox_key", C.c_uint64), ("seed", C.c_char_p)]
+
+
+CHUNK_RES, CHUNK_VOXELS, CHUNK_DRAWS_PER_STEP, CHUNK_TERMS = 32, 32 ** 3, 8, 12
+CHUNK_TERM_NAMES = ["traversability", "geological", "overhang", "erosion", "aesthetics", "caves", "performance",
+                    "biomeTransition", "total", "cave_reach", "underground_air", "solid"]
+
 
 class GraphInfo(C.Structure):
     _fields_ = [("incremental", C.c_int32), ("lds_placement", C.c_int32), ("cluster_size", C.c_int32),
@@ -120,6 +136,22 @@ def load():
     L.pt_graph_stream.restype = vp
     L.pt_graph_stream.argtypes = [vp]
     L.pt_debug_canonical_sum.argtypes = [vp, i64, C.POINTER(dbl), C.POINTER(i32)]
+    L.pt_chunk_default_config.restype = None
+    L.pt_chunk_default_config.argtypes = [C.POINTER(ChunkConfig), i32, i32]
+    L.pt_chunk_create.argtypes = [C.POINTER(ChunkConfig), C.POINTER(vp)]
+    L.pt_chunk_destroy.restype = None
+    L.pt_chunk_destroy.argtypes = [vp]
+    L.pt_chunk_upload.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.pt_chunk_set_draws.argtypes = [vp, vp, i64, vp, i64]
+    L.pt_chunk_enable_trace.argtypes = [vp, i64, i64]
+    L.pt_chunk_read_trace.argtypes = [vp, vp, i64, vp, i64]
+    L.pt_chunk_run.argtypes = [vp, i64]
+    L.pt_chunk_sync.argtypes = [vp]
+    L.pt_chunk_download.argtypes = [vp, vp, vp, vp, vp]
+    L.pt_chunk_replica_slots.argtypes = [vp, vp]
+    L.pt_chunk_cost_terms.argtypes = [vp, vp]
+    L.pt_chunk_get_stats.argtypes = [vp, C.POINTER(GraphStats)]
+    L.pt_chunk_kernel_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), i32]
     L.pt_geometric_ladder.restype = C.c_int
     L.pt_geometric_ladder.argtypes = [dbl, dbl, i32, C.POINTER(dbl)]
     L.pt_swap_frequency.restype = i32
