@@ -35,7 +35,32 @@ def case_workload(c):
     return wl
 
 
+CHUNK_CASE = dict(chunks=1, T=3, iters=300, f=11, seed="golden-chunk")
+
+
+def chunk_workload():
+    return wlm.chunk_workload("golden", CHUNK_CASE["chunks"], CHUNK_CASE["T"])
+
+
+def make_chunk():
+    """Voxel-chunk run (terrain oracle): the trace and the final costs only (the fields are 384 KB per replica)."""
+    import terrain_binding as tb
+    c = CHUNK_CASE
+    wl = chunk_workload()
+    o = tb.run(wl["density"][0], wl["moisture"][0], wl["temperature"][0], wl["material"][0], wl["temperatures"][0],
+               c["iters"], c["f"], tb.default_config(ob.SUM_CANONICAL), key=int(ob.lib().og_seed_key(c["seed"].encode())))
+    assert o["err"] == 0
+    tr = o["trace"]
+    np.savez_compressed(os.path.join(HERE, "chunk.npz"), kind=tr["kind"].astype(np.int8), a=tr["a"].astype(np.int32),
+                        b=tr["b"].astype(np.int8), flags=tr["flags"].astype(np.uint8), reach0=tr["reach0"].astype(np.int32),
+                        reach_origin=tr["reach_origin"].astype(np.int32), cost_after=tr["cost_after"],
+                        swap_trace=o["swap_trace"], cost=o["cost"],
+                        density_sum=o["density"].astype(np.float64).sum(axis=1))
+    print("chunk accepted", int(((tr["flags"] & 4) != 0).sum()), "of", tr["flags"].size, "swaps", int(o["swap_trace"].sum()))
+
+
 def main():
+    make_chunk()
     for name, c in CASES.items():
         wl = case_workload(c)
         o = pu.oracle_run(wl, c["iters"], c["f"], seed=c["seed"])[0]
