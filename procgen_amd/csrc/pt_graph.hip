@@ -336,7 +336,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     A(e->queue, sizeof(int) * (size_t)R * 2 * N);
     A(e->bitmap, bitmap_in_lds ? 16 : sizeof(unsigned) * (size_t)R * nwords);
     const int collcap = 64;     // deferred collisions per thread; more are priced on the spot
-    A(e->collbuf, sizeof(float) * (size_t)R * C * collcap * 1024);
+    A(e->collbuf, sizeof(float) * (size_t)R * C * collcap * block);
     A(e->stats, sizeof(unsigned long long) * (size_t)R * 4);
     A(e->swap_stats, sizeof(unsigned long long) * (size_t)e->G * 2);
     A(e->status, sizeof(unsigned));
@@ -390,7 +390,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         P.inv_cell_f = P.cell_pow2 ? (float)(1.0 / cfg->min_distance) : 0.0f;
         P.d2_hi = first_float_where([&](float s) { return (double)sqrtf(s) >= cfg->min_distance; });
         P.d2_lo = first_float_where([&](float s) { return (double)sqrtf(s) > cfg->min_distance_eps; });
-        P.collcap = collcap;
+        P.collcap = collcap; P.collstride = block;
     }
     P.key0 = (uint32_t)key; P.key1 = (uint32_t)(key >> 32);
     P.px = e->px.as<float>(); P.py = e->py.as<float>(); P.pz = e->pz.as<float>();

@@ -37,7 +37,7 @@ struct GraphParams {
     // cost
     double w[6], target_len, min_dist, eps, inv_cell;
     float inv_cell_f, d2_hi, d2_lo;     // see cell_coord() and the collision test
-    int cell_pow2, collcap;
+    int cell_pow2, collcap, collstride;     // collstride: threads per workgroup (rows of the deferred-collision lists)
     uint32_t key0, key1;
     // state, replica-major
     float *px, *py, *pz;        // [R][N]
@@ -59,7 +59,7 @@ struct GraphParams {
     int *sorted;                // [R][N]
     int *queue;                 // [R][2][N]
     unsigned *bitmap;           // [R][nwords] (when not in LDS)
-    float *collbuf;             // [R][C][collcap][1024]
+    float *collbuf;             // [R][C][collcap][collstride]
     // draws
     const double *chain_u;      // [G][Tl][draw_steps][6]
     long long draw_steps;
