@@ -82,6 +82,16 @@ void parallel_tempering_step_f32(float *positions, int *edges, float *costs, flo
  * its static device buffers, src/gpu/parallel_tempering.cu:139-146). */
 void parallel_tempering_reset(void);
 
+/* Replaces the reference export of the same name (reference src/GPU.Compute.fs:42-49, caller
+ * src/GPU.Wrappers.fs:347-416): all pairs i < j with 0.001 < |p_j - p_i| < minDistance (fp32 distance,
+ * the predicate of the host's CPU routine, reference src/SpatialHash.fs:89-146), written as
+ * i0,j0,i1,j1,... sorted by (i, j); out_count[0] = number of pairs.  F# `float` is System.Double, so the
+ * unchanged host marshals double*: collision_detection takes doubles, collision_detection_f32 floats.
+ * The host's buffer holds nodeCount * nodeCount / 2 pairs.  On failure the outputs are left untouched
+ * (pt_last_error tells why). */
+void collision_detection(const double *positions, int *collision_pairs, int node_count, double min_distance, int *out_count);
+void collision_detection_f32(const float *positions, int *collision_pairs, int node_count, float min_distance, int *out_count);
+
 /* ---- batched spatial-graph engine --------------------------------------- */
 
 typedef struct pt_graph_engine pt_graph_engine;

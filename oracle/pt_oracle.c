@@ -368,6 +368,18 @@ static void brute_pairs(const float *pos, int n, double min_dist, double eps, pa
         }
 }
 
+/* SpatialHash.detectCollisions as a pair list (brute force, :89-101), pairs sorted by (i, j).
+ * Returns the number of pairs found; writes at most cap of them. */
+int64_t og_collision_pairs(const float *pos, int n, double min_dist, double eps, int32_t *out, int64_t cap)
+{
+    pairvec pv = {0};
+    brute_pairs(pos, n, min_dist, eps, &pv);
+    for (int64_t k = 0; k < pv.n && k < cap; k++) { out[2 * k] = pv.p[k].i; out[2 * k + 1] = pv.p[k].j; }
+    int64_t found = pv.n;
+    free(pv.p);
+    return found;
+}
+
 static inline int cell_of(float x, double cell) { return (int)((double)x / cell); }  /* truncation, SpatialHash.fs:113-116 */
 
 static inline uint32_t cell_hash(int cx, int cy, int cz)

@@ -107,6 +107,8 @@ double og_cost(const og_graph *g, const og_config *c, og_terms *out);
 
 int og_count_reachable(int n, const int32_t *edges, int e, int start, int algo);
 double og_collision_penalty(const float *pos, int n, const og_config *c, int64_t *npairs, int *err);
+/* SpatialHash.detectCollisions (SpatialHash.fs:89-101 predicate) as a list of pairs i < j in (i, j) order */
+int64_t og_collision_pairs(const float *pos, int n, double min_dist, double eps, int32_t *out, int64_t cap);
 
 /* ---- scalar pieces ------------------------------------------------------ */
 void og_geometric_ladder(double tmin, double tmax, int n, double *out, int *out_n);

@@ -9,6 +9,7 @@ drop-in entry point can be exercised exactly the way that host drives it:
   Marshaling.*                    reference GPU.Wrappers.fs:191-244
   GPUTempering.validateGraph      reference GPU.Wrappers.fs:250-258
   GPUTempering.optimize           reference GPU.Wrappers.fs:271-344  (one native call per iteration)
+  GPUCollision.detect             reference GPU.Wrappers.fs:347-416
   Dispatch.useGPU / optimize      reference GPU.Wrappers.fs:689-724
 
 plus `optimize_batched`, the one-call replacement the reference's glue could switch to.
@@ -180,6 +181,37 @@ class GPUTempering:
                 res = eng.download(edges=False)
             GPUTempering.last_costs = res["cost"][0]
             return Ok([SpatialGraph(g.Nodes, res["pos"][0, i], list(g.Edges)) for i, g in enumerate(graphs)])
+        except Exception as ex:
+            return Error("NativeException", str(ex))
+
+
+class GPUCollision:
+    @staticmethod
+    def detect(minDistance: float, graph: SpatialGraph):
+        """reference GPU.Wrappers.fs:381-416 (validation) and :349-379 (the native call): the pairs come
+        back as (i, j) tuples.  Without a device the reference falls back to its CPU spatial hash; this
+        library has no CPU path, so that case is an error here."""
+        if minDistance <= 0.0 or math.isnan(minDistance) or math.isinf(minDistance):
+            return Error("InvalidArgument", f"minDistance must be positive and finite, got {minDistance}")
+        if len(graph.Positions) != len(graph.Nodes):
+            return Error("InvalidArgument", f"Position count {len(graph.Positions)} != Node count {len(graph.Nodes)}")
+        if not Wrappers.available():
+            return Error("DeviceNotAvailable", "GPU device not available")
+        try:
+            lib = nt.load()
+            n = len(graph.Nodes)
+            max_collisions = n * n // 2
+            if max_collisions > (2 ** 31 - 1) // 2:
+                return Error("BufferOverflow", f"Too many potential collisions: {max_collisions}")
+            positions = Marshaling.flattenVec3(graph.Positions)
+            pairs = np.zeros(max(max_collisions, 1) * 2, np.int32)
+            count = np.zeros(1, np.int32)
+            lib.collision_detection(nt.ptr(positions), nt.ptr(pairs), n, float(minDistance), nt.ptr(count))
+            if lib.pt_last_error() != 0:
+                raise nt.PtError(lib.pt_last_error(), (lib.pt_last_error_string() or b"").decode())
+            if count[0] < 0 or count[0] > max_collisions:
+                return Error("BufferOverflow", f"Invalid collision count: {count[0]}")
+            return Ok([(int(a), int(b)) for a, b in pairs[:2 * count[0]].reshape(-1, 2)])
         except Exception as ex:
             return Error("NativeException", str(ex))
 

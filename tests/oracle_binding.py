@@ -159,6 +159,19 @@ def cost(pos, edges, kind, value, cfg):
     return t
 
 
+def collision_pairs(pos, min_dist, eps=0.001):
+    """All pairs i < j with eps < dist < min_dist, sorted (the reference's CPU detectCollisions as a set)."""
+    L = lib()
+    L.og_collision_pairs.restype = C.c_int64
+    L.og_collision_pairs.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int32), C.c_int64]
+    p = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+    n = p.shape[0]
+    cap = max(n * n // 2, 1)
+    out = np.zeros((cap, 2), np.int32)
+    found = L.og_collision_pairs(_p(p, C.c_float), n, min_dist, eps, _p(out, C.c_int32), cap)
+    return out[:found]
+
+
 def count_reachable(n, edges, start, algo=ALGO_FAITHFUL):
     edges = np.ascontiguousarray(edges, np.int32).reshape(-1, 2)
     return lib().og_count_reachable(n, _p(edges, C.c_int32), edges.shape[0], start, algo)
