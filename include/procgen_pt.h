@@ -248,6 +248,50 @@ typedef struct pt_graph_info_rec {
 } pt_graph_info_rec;
 int pt_graph_info(pt_graph_engine *e, pt_graph_info_rec *out);
 
+/* ---- convergence monitoring ---------------------------------------------- */
+/* Convergence.ConvergenceMetrics (reference src/ParallelTempering.Core.fs:315-322); the two
+ * options are a flag and a value. */
+typedef struct pt_convergence_metrics {
+    double gelman_rubin;            /* valid when has_gelman_rubin */
+    double effective_sample_size;   /* valid when has_ess; of chain 0, as the reference takes it */
+    double cost_stabilization;
+    double swap_acceptance_rate;
+    int32_t has_gelman_rubin, has_ess, has_converged, iteration;
+} pt_convergence_metrics;
+
+/* Replaces Convergence.initHistory / updateHistory (reference src/ParallelTempering.Core.fs:333-356):
+ * from the next step on the device keeps, per ladder, the last window_size costs of every chain
+ * (taken after the swap pass on swap steps) and the last window_size swap outcomes.  Calling it
+ * again empties the history.  Full ladders only (temp_offset 0, temp_local = temp_count). */
+int pt_graph_enable_convergence(pt_graph_engine *e, int32_t window_size);
+/* Convergence.checkConvergence (reference src/ParallelTempering.Core.fs:442-492) on the device,
+ * one record per ladder; `iteration` is copied into the records.  Synchronises. */
+int pt_graph_check_convergence(pt_graph_engine *e, double strictness, int32_t iteration, pt_convergence_metrics *out);
+/* Convergence.runUntilConvergence (reference src/ParallelTempering.Core.fs:496-550): steps from
+ * the engine's current step up to max_iterations, checking after every step s with
+ * s % check_freq == 0 and s > window/2, and stops as soon as EVERY ladder has converged (the
+ * reference runs one ladder).  The history window is max(200, max_iterations/10) unless
+ * pt_graph_enable_convergence was called before.  out[group_count] holds the last check (the
+ * final one at max_iterations when no earlier check stopped the run); *steps_done the steps run. */
+int pt_graph_run_until_converged(pt_graph_engine *e, int64_t max_iterations, int32_t check_freq, double strictness,
+                                 int64_t *steps_done, pt_convergence_metrics *out);
+
+/* Replaces the extern declared at reference src/GPU.Compute.fs:98-109 (implemented by
+ * src/gpu/convergence.cu:255-363; no host code calls it).  The argument types are the ones the
+ * F# declaration marshals: float[] and float are doubles, bool[] arrives as 4-byte elements, the
+ * record is four floats and two ints (:88-96).  costHistory is [numChains][historyLength], oldest
+ * sample first; historyLength doubles as the window size.  The statistics are the host routine's
+ * (src/ParallelTempering.Core.fs:442-492), evaluated in fp64 and rounded into the record; an
+ * absent statistic reads as the CUDA routine's placeholder (2.0 for R-hat, 1.0 for ESS).
+ * The call completes before it returns (the record is host memory); `stream` is ignored. */
+typedef struct ConvergenceMetrics {
+    float GelmanRubin, EffectiveSampleSize, CostStabilization, AvgSwapAcceptance;
+    int32_t Iteration, HasConverged;
+} ConvergenceMetrics;
+void check_convergence_async(const double *costHistory, const int32_t *swapHistory, int numChains, int historyLength,
+                             int swapHistoryLength, double strictness, int iteration, ConvergenceMetrics *outMetrics,
+                             void *stream);
+
 /* ======================================================================================
  * Voxel-chunk engine: parallel tempering over 32^3 terrain chunks.
  *

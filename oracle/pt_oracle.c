@@ -751,3 +751,146 @@ int og_run(const og_run_args *a, const og_config *c)
     free(ch);
     return err;
 }
+
+/* ---- Convergence (reference src/ParallelTempering.Core.fs:312-492) ------------------------- */
+struct og_conv_history {
+    int chains, window;
+    double **costs;     /* per chain, oldest first */
+    int *count;
+    uint8_t *swaps;     /* oldest first */
+    int nswaps;
+};
+
+og_conv_history *og_conv_new(int chains, int window)
+{
+    og_conv_history *h = calloc(1, sizeof *h);
+    h->chains = chains; h->window = window;
+    h->costs = calloc((size_t)(chains > 0 ? chains : 1), sizeof *h->costs);
+    h->count = calloc((size_t)(chains > 0 ? chains : 1), sizeof *h->count);
+    for (int c = 0; c < chains; c++) h->costs[c] = malloc(sizeof(double) * (size_t)(window + 1));
+    h->swaps = NULL; h->nswaps = 0;
+    return h;
+}
+
+void og_conv_free(og_conv_history *h)
+{
+    if (!h) return;
+    for (int c = 0; c < h->chains; c++) free(h->costs[c]);
+    free(h->costs); free(h->count); free(h->swaps); free(h);
+}
+
+void og_conv_update(og_conv_history *h, const double *chain_costs, const uint8_t *outcomes, int n_outcomes)
+{
+    for (int c = 0; c < h->chains; c++) {                   /* :344-349 */
+        h->costs[c][h->count[c]++] = chain_costs[c];
+        if (h->count[c] > h->window) {
+            memmove(h->costs[c], h->costs[c] + 1, sizeof(double) * (size_t)(h->count[c] - 1));
+            h->count[c]--;
+        }
+    }
+    if (n_outcomes > 0) {                                   /* :531 prepends, :352 appends the list */
+        h->swaps = realloc(h->swaps, (size_t)(h->nswaps + n_outcomes));
+        for (int k = 0; k < n_outcomes; k++) h->swaps[h->nswaps + k] = outcomes[n_outcomes - 1 - k];
+        h->nswaps += n_outcomes;
+    }
+    while (h->nswaps > h->window) {                         /* :353-354 */
+        memmove(h->swaps, h->swaps + 1, (size_t)(h->nswaps - 1));
+        h->nswaps--;
+    }
+}
+
+static double conv_average(const double *x, int n)
+{
+    double s = 0.0;
+    for (int i = 0; i < n; i++) s += x[i];
+    return s / (double)n;
+}
+
+static double conv_sum_sq_dev(const double *x, int n, double mean)
+{
+    double s = 0.0;
+    for (int i = 0; i < n; i++) { double d = x[i] - mean; s += d * d; }    /* (x - mean) ** 2.0 */
+    return s;
+}
+
+void og_conv_check(const og_conv_history *h, int iteration, double strictness, og_conv_metrics *out)
+{
+    memset(out, 0, sizeof *out);
+    out->iteration = iteration;
+    const int mch = h->chains;
+    /* gelmanRubin :360-394 */
+    if (mch >= 2) {
+        int minlen = h->count[0];
+        for (int c = 1; c < mch; c++) if (h->count[c] < minlen) minlen = h->count[c];
+        const double n = (double)minlen, m = (double)mch;
+        if (n >= 10.0) {
+            double *means = malloc(sizeof(double) * (size_t)mch), *vars = malloc(sizeof(double) * (size_t)mch);
+            for (int c = 0; c < mch; c++) {
+                const double *smp = h->costs[c] + (h->count[c] - minlen);
+                means[c] = conv_average(smp, minlen);
+                vars[c] = (1.0 / (n - 1.0)) * conv_sum_sq_dev(smp, minlen, means[c]);
+            }
+            const double grand = conv_average(means, mch);
+            const double B = (n / (m - 1.0)) * conv_sum_sq_dev(means, mch, grand);
+            const double W = conv_average(vars, mch);
+            out->has_gelman_rubin = 1;
+            if (W > 1e-10) {
+                const double var_plus = ((n - 1.0) / n) * W + (1.0 / n) * B;
+                out->gelman_rubin = sqrt(var_plus / W);
+            } else out->gelman_rubin = 1.0;
+            free(means); free(vars);
+        }
+    }
+    /* effectiveSampleSize :397-426 on chain 0 (:447-450) */
+    if (mch > 0 && h->count[0] > 0 && h->count[0] >= 20) {
+        const int n = h->count[0];
+        const double *x = h->costs[0];
+        const double mean = conv_average(x, n);
+        const double variance = conv_sum_sq_dev(x, n, mean) / (double)n;
+        out->has_ess = 1;
+        if (variance < 1e-10) out->effective_sample_size = (double)n;
+        else {
+            const int max_lag = n / 3 < 50 ? n / 3 : 50;
+            double rho_sum = 0.0;
+            int k = 1;
+            while (k < max_lag) {
+                double s = 0.0;
+                for (int i = 0; i < n - k; i++) s += (x[i] - mean) * (x[i + k] - mean);
+                const double rho = s / ((double)(n - k) * variance);
+                if (rho > 0.05) { rho_sum += rho; k++; } else k = max_lag;
+            }
+            const double ess = (double)n / (1.0 + 2.0 * rho_sum);
+            out->effective_sample_size = ess != ess ? ess : (ess > 1.0 ? ess : 1.0);
+        }
+    }
+    /* :453-462 */
+    {
+        const int rw = h->window / 5 < 50 ? h->window / 5 : 50;
+        int total = 0;
+        for (int c = 0; c < mch; c++) total += h->count[c] >= rw ? rw : h->count[c];
+        if (total == 0) out->cost_stabilization = 1.0;
+        else {
+            double *all = malloc(sizeof(double) * (size_t)total);
+            int w = 0;
+            for (int c = 0; c < mch; c++) {
+                const int take = h->count[c] >= rw ? rw : h->count[c];
+                memcpy(all + w, h->costs[c] + (h->count[c] - take), sizeof(double) * (size_t)take);
+                w += take;
+            }
+            const double mean = conv_average(all, total);
+            if (fabs(mean) < 1e-10) out->cost_stabilization = 0.0;
+            else out->cost_stabilization = sqrt(conv_sum_sq_dev(all, total, mean) / (double)total) / fabs(mean);
+            free(all);
+        }
+    }
+    /* :465-470 */
+    if (h->nswaps > 0) {
+        int yes = 0;
+        for (int i = 0; i < h->nswaps; i++) yes += h->swaps[i] ? 1 : 0;
+        out->swap_acceptance_rate = (double)yes / (double)h->nswaps;
+    }
+    const int swap_quality = out->swap_acceptance_rate >= 0.2 && out->swap_acceptance_rate <= 0.4;
+    const double rhat_threshold = 1.2 - strictness * 0.19, cv_threshold = 0.1 - strictness * 0.09;
+    out->has_converged = out->has_gelman_rubin && out->has_ess && out->gelman_rubin < rhat_threshold &&
+                         out->cost_stabilization < cv_threshold && out->effective_sample_size > 50.0 && swap_quality;
+}

@@ -110,6 +110,20 @@ double og_collision_penalty(const float *pos, int n, const og_config *c, int64_t
 /* SpatialHash.detectCollisions (SpatialHash.fs:89-101 predicate) as a list of pairs i < j in (i, j) order */
 int64_t og_collision_pairs(const float *pos, int n, double min_dist, double eps, int32_t *out, int64_t cap);
 
+/* ---- Convergence (reference src/ParallelTempering.Core.fs:312-492) --------- */
+typedef struct og_conv_history og_conv_history;
+typedef struct og_conv_metrics {
+    double gelman_rubin, effective_sample_size, cost_stabilization, swap_acceptance_rate;
+    int32_t has_gelman_rubin, has_ess, has_converged, iteration;
+} og_conv_metrics;
+og_conv_history *og_conv_new(int chains, int window);                  /* initHistory :333-339 */
+void og_conv_free(og_conv_history *h);
+/* updateHistory :342-356 as runUntilConvergence calls it (:523-536): chain_costs[chains] after the
+ * step (after the swap pass when there was one); outcomes[n_outcomes] in PAIR order 0..T-2, which
+ * the reference prepends one by one and so appends to the history last pair first. */
+void og_conv_update(og_conv_history *h, const double *chain_costs, const uint8_t *outcomes, int n_outcomes);
+void og_conv_check(const og_conv_history *h, int iteration, double strictness, og_conv_metrics *out);  /* :442-492 */
+
 /* ---- scalar pieces ------------------------------------------------------ */
 void og_geometric_ladder(double tmin, double tmax, int n, double *out, int *out_n);
 int og_swap_frequency(int node_count);

@@ -43,7 +43,10 @@ struct pt_graph_engine {
     SwapParams SP;
     DevBuf px, py, pz, ea, eb, et, ebuf, ecount, kind, value, origin, terminal, rowend, adj, adj4, cost, temps,
         slot_of_rep, rep_of_slot, cells, sorted, queue, bitmap, collbuf, comm, chain_u, swap_u, trace, swap_trace,
-        stats, swap_stats, status, terms, dacc, dreach, dvis, dparent, dparscr, dlabel, dlabscr, epk;
+        stats, swap_stats, status, terms, dacc, dreach, dvis, dparent, dparscr, dlabel, dlabscr, epk,
+        conv_hist, conv_swaps, conv_swap_total, conv_out;
+    int conv_window = 0;            // 0: convergence monitoring off
+    long long conv_first_step = 0;  // first step the history holds
     long long step = 0;
     long long trace_steps = 0, trace_passes = 0;
     bool uploaded = false;
@@ -148,6 +151,81 @@ int launch_swap(pt_graph_engine *e, long long pass, const double *d_energy)
     int threads = 64, blocks = (e->G + threads - 1) / threads;
     hipLaunchKernelGGL(pt_graph_swap_kernel, dim3(blocks), dim3(threads), 0, e->stream, sp, pass);
     PT_HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+// Steps [step, step+n) of the loop at reference src/ParallelTempering.Core.fs:162-177: the swap
+// pass follows every step whose index is a multiple of f.  The caller holds the engine's lock.
+int run_steps(pt_graph_engine *e, long long steps)
+{
+    long long s = e->step, end = e->step + steps;
+    const long long f = e->f;
+    while (s < end) {
+        long long next_swap_step = ((s + f - 1) / f) * f;         // first multiple of f that is >= s
+        long long last = std::min(end - 1, next_swap_step);       // run through `last` inclusive
+        int n = (int)(last - s + 1);
+        int rc = launch_steps(e, s, n);
+        if (rc) return rc;
+        s = last + 1;
+        if (last == next_swap_step && e->Tl > 1) {
+            rc = launch_swap(e, last / f, e->cost.as<double>());
+            if (rc) return rc;
+        }
+    }
+    e->step = end;
+    return PT_OK;
+}
+
+int enable_convergence(pt_graph_engine *e, int window)
+{
+    PT_HIP_TRY(hipStreamSynchronize(e->stream));
+    PT_HIP_TRY(e->conv_hist.alloc(sizeof(double) * (size_t)e->G * e->Tl * window));
+    PT_HIP_TRY(e->conv_swaps.alloc((size_t)e->G * window));
+    PT_HIP_TRY(e->conv_swap_total.alloc(sizeof(unsigned long long) * (size_t)e->G));
+    PT_HIP_TRY(e->conv_out.alloc(sizeof(pt_convergence_metrics) * (size_t)e->G));
+    PT_HIP_TRY(hipMemset(e->conv_hist.p, 0, e->conv_hist.bytes));
+    PT_HIP_TRY(hipMemset(e->conv_swaps.p, 0, e->conv_swaps.bytes));
+    PT_HIP_TRY(hipMemset(e->conv_swap_total.p, 0, e->conv_swap_total.bytes));
+    e->conv_window = window;
+    e->conv_first_step = e->step;
+    e->P.conv_hist = e->conv_hist.as<double>(); e->P.conv_window = window;
+    e->SP.conv_hist = e->conv_hist.as<double>(); e->SP.conv_window = window;
+    e->SP.conv_swaps = e->conv_swaps.as<uint8_t>();
+    e->SP.conv_swap_total = e->conv_swap_total.as<unsigned long long>();
+    e->SP.swap_frequency = e->f;
+    return PT_OK;
+}
+
+int launch_convergence(hipStream_t stream, const ConvParams &cp)
+{
+    const size_t lds = sizeof(double) * (2 * (size_t)cp.chains + PT_WAVE);
+    if (lds > 60000) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "too many chains for the convergence check");
+    hipLaunchKernelGGL(pt_graph_convergence_kernel, dim3((unsigned)cp.ladders), dim3(PT_WAVE), lds, stream, cp);
+    PT_HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+int check_convergence(pt_graph_engine *e, double strictness, int iteration, pt_convergence_metrics *out)
+{
+    const long long recorded = e->step - e->conv_first_step;
+    ConvParams cp;
+    std::memset(&cp, 0, sizeof cp);
+    cp.hist = e->conv_hist.as<double>();
+    cp.ring = e->conv_window;
+    cp.chain_stride = e->conv_window;
+    cp.ladder_stride = (long long)e->conv_window * e->Tl;
+    cp.n = (int)std::min<long long>(recorded, e->conv_window);
+    cp.first = (int)((e->step - cp.n) % e->conv_window);
+    cp.chains = e->Tl; cp.window = e->conv_window; cp.ladders = e->G;
+    cp.swaps = e->conv_swaps.as<uint8_t>();
+    cp.swap_total = e->conv_swap_total.as<unsigned long long>();
+    cp.swap_ring = e->conv_window;
+    cp.strictness = strictness; cp.iteration = iteration;
+    cp.out = e->conv_out.as<pt_convergence_metrics>();
+    int rc = launch_convergence(e->stream, cp);
+    if (rc) return rc;
+    PT_HIP_TRY(hipMemcpyAsync(out, e->conv_out.p, sizeof(pt_convergence_metrics) * (size_t)e->G, hipMemcpyDeviceToHost, e->stream));
+    PT_HIP_TRY(hipStreamSynchronize(e->stream));
     return PT_OK;
 }
 
@@ -503,6 +581,7 @@ int pt_graph_upload(pt_graph_engine *e, const float *positions, const int32_t *e
     (void)T;
 
     e->step = 0;
+    if (e->conv_window) { int rc = enable_convergence(e, e->conv_window); if (rc) return rc; }
     { int rc = launch_init(e, e->P, 1); if (rc) return rc; }
     PT_HIP_TRY(hipStreamSynchronize(st));
     e->uploaded = true;
@@ -571,22 +650,7 @@ int pt_graph_run(pt_graph_engine *e, int64_t steps)
     if (e->Tl != e->T) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "split ladder: use pt_graph_run_to_swap_point / pt_graph_swap_pass");
     std::lock_guard<std::mutex> lock(e->mu);
     DeviceGuard guard(e->device);
-    long long s = e->step, end = e->step + steps;
-    const long long f = e->f;
-    while (s < end) {
-        long long next_swap_step = ((s + f - 1) / f) * f;         // first multiple of f that is >= s
-        long long last = std::min(end - 1, next_swap_step);       // run through `last` inclusive
-        int n = (int)(last - s + 1);
-        int rc = launch_steps(e, s, n);
-        if (rc) return rc;
-        s = last + 1;
-        if (last == next_swap_step && e->Tl > 1) {
-            rc = launch_swap(e, last / f, e->cost.as<double>());
-            if (rc) return rc;
-        }
-    }
-    e->step = end;
-    return PT_OK;
+    return run_steps(e, steps);
 }
 
 // Set the index of the next step (the swap schedule and the draw addresses follow it).
@@ -599,6 +663,68 @@ int pt_graph_set_step(pt_graph_engine *e, int64_t step)
     PT_HIP_TRY(hipStreamSynchronize(e->stream));
     PT_HIP_TRY(hipMemset(e->comm.p, 0, e->comm.bytes));     // hand-off tags restart with the step counter
     e->step = step;
+    if (e->conv_window) return enable_convergence(e, e->conv_window);   // the history does not span the jump
+    return PT_OK;
+}
+
+int pt_graph_enable_convergence(pt_graph_engine *e, int32_t window_size)
+{
+    pt::clear_error();
+    if (!e || window_size < 1) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null engine or window_size < 1");
+    if (e->Tl != e->T) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "convergence monitoring needs the full ladder in one engine");
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    return enable_convergence(e, window_size);
+}
+
+int pt_graph_check_convergence(pt_graph_engine *e, double strictness, int32_t iteration, pt_convergence_metrics *out)
+{
+    pt::clear_error();
+    if (!e || !out) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null argument");
+    if (!e->conv_window) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "pt_graph_check_convergence before pt_graph_enable_convergence");
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    return check_convergence(e, strictness, iteration, out);
+}
+
+int pt_graph_run_until_converged(pt_graph_engine *e, int64_t max_iterations, int32_t check_freq, double strictness,
+                                 int64_t *steps_done, pt_convergence_metrics *out)
+{
+    pt::clear_error();
+    if (!e || !out || max_iterations < 0 || check_freq < 1)
+        return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null argument, negative max_iterations or check_freq < 1");
+    if (!e->uploaded) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "run before upload");
+    if (e->Tl != e->T) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "convergence monitoring needs the full ladder in one engine");
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    if (!e->conv_window) {
+        // reference src/ParallelTempering.Core.fs:512
+        const long long w = std::max<long long>(200, max_iterations / 10);
+        if (w > 0x3fffffff) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "history window too large");
+        int rc = enable_convergence(e, (int)w);
+        if (rc) return rc;
+    }
+    const long long start = e->step, half = e->conv_window / 2;
+    bool stopped = false;
+    while (e->step < max_iterations && !stopped) {
+        // first step index c >= step with c % check_freq == 0 and c > window/2 (:539)
+        long long c = std::max(e->step, half + 1);
+        c = (c + check_freq - 1) / check_freq * check_freq;
+        const long long last = std::min<long long>(c, max_iterations - 1);
+        int rc = run_steps(e, last - e->step + 1);
+        if (rc) return rc;
+        if (last == c) {
+            rc = check_convergence(e, strictness, (int)c, out);
+            if (rc) return rc;
+            stopped = true;
+            for (int g = 0; g < e->G; g++) stopped = stopped && out[g].has_converged;
+        }
+    }
+    if (!stopped) {     // :516-519
+        int rc = check_convergence(e, strictness, (int)std::max<long long>(e->step, max_iterations), out);
+        if (rc) return rc;
+    }
+    if (steps_done) *steps_done = e->step - start;
     return PT_OK;
 }
 
@@ -831,6 +957,55 @@ int pt_debug_canonical_sum(const double *terms, int64_t n, double *out, int32_t 
     PT_HIP_TRY(hipMemcpy(&herr, er.p, sizeof herr, hipMemcpyDeviceToHost));
     if (range_error) *range_error = (int32_t)herr;
     return PT_OK;
+}
+
+// Replaces the extern at reference src/GPU.Compute.fs:98-109; the statistics follow the host
+// routine (src/ParallelTempering.Core.fs:442-492).
+void check_convergence_async(const double *costHistory, const int32_t *swapHistory, int numChains, int historyLength,
+                             int swapHistoryLength, double strictness, int iteration, ConvergenceMetrics *outMetrics,
+                             void *stream)
+{
+    (void)stream;
+    pt::clear_error();
+    if (!outMetrics) { pt::set_error(PT_ERR_INVALID_ARGUMENT, "null outMetrics"); return; }
+    // what the CUDA routine leaves when it has too little history (src/gpu/convergence.cu:293-300)
+    outMetrics->GelmanRubin = 2.0f; outMetrics->EffectiveSampleSize = 1.0f; outMetrics->CostStabilization = 1.0f;
+    outMetrics->AvgSwapAcceptance = 0.0f; outMetrics->Iteration = iteration; outMetrics->HasConverged = 0;
+    if (numChains < 0 || historyLength < 0 || swapHistoryLength < 0 || (numChains > 0 && historyLength > 0 && !costHistory) ||
+        (swapHistoryLength > 0 && !swapHistory)) {
+        pt::set_error(PT_ERR_INVALID_ARGUMENT, "negative length or null history");
+        return;
+    }
+    auto run = [&]() -> int {
+        DevBuf hist, swaps, out;
+        const size_t nh = (size_t)numChains * (size_t)historyLength;
+        PT_HIP_TRY(hist.alloc(sizeof(double) * std::max<size_t>(nh, 1)));
+        PT_HIP_TRY(swaps.alloc(std::max<size_t>((size_t)swapHistoryLength, 1)));
+        PT_HIP_TRY(out.alloc(sizeof(pt_convergence_metrics)));
+        if (nh) PT_HIP_TRY(hipMemcpy(hist.p, costHistory, sizeof(double) * nh, hipMemcpyHostToDevice));
+        std::vector<uint8_t> sw((size_t)swapHistoryLength);
+        for (int i = 0; i < swapHistoryLength; i++) sw[(size_t)i] = swapHistory[i] != 0;
+        if (swapHistoryLength) PT_HIP_TRY(hipMemcpy(swaps.p, sw.data(), sw.size(), hipMemcpyHostToDevice));
+        ConvParams cp;
+        std::memset(&cp, 0, sizeof cp);
+        cp.hist = hist.as<double>();
+        cp.ring = std::max(historyLength, 1); cp.chain_stride = historyLength; cp.ladder_stride = 0;
+        cp.first = 0; cp.n = historyLength; cp.chains = numChains; cp.window = historyLength; cp.ladders = 1;
+        cp.swaps = swaps.as<uint8_t>(); cp.swap_total = nullptr; cp.swap_ring = std::max(swapHistoryLength, 1); cp.swap_n = swapHistoryLength;
+        cp.strictness = strictness; cp.iteration = iteration;
+        cp.out = out.as<pt_convergence_metrics>();
+        int rc = launch_convergence(nullptr, cp);
+        if (rc) return rc;
+        pt_convergence_metrics m;
+        PT_HIP_TRY(hipMemcpy(&m, out.p, sizeof m, hipMemcpyDeviceToHost));
+        if (m.has_gelman_rubin) outMetrics->GelmanRubin = (float)m.gelman_rubin;
+        if (m.has_ess) outMetrics->EffectiveSampleSize = (float)m.effective_sample_size;
+        outMetrics->CostStabilization = (float)m.cost_stabilization;
+        outMetrics->AvgSwapAcceptance = (float)m.swap_acceptance_rate;
+        outMetrics->HasConverged = m.has_converged;
+        return PT_OK;
+    };
+    (void)run();
 }
 
 }  // extern "C"

@@ -79,6 +79,9 @@ struct GraphParams {
     unsigned *dlabscr;          // [R][N]  scratch: labels found while a proposal is evaluated
     unsigned *epk;              // [R][epk_stride]  scratch: the edge list packed as a | b << 16
     int epk_stride;             // edges-per-thread bound times the workgroup size
+    // convergence monitoring (null when off): cost of every chain after every step, a ring per chain
+    double *conv_hist;          // [G][Tl][conv_window], step s at index s % conv_window
+    int conv_window;
 };
 
 struct SwapParams {
@@ -94,4 +97,23 @@ struct SwapParams {
     long long trace_passes;
     unsigned long long *swap_stats; // [G][2] attempts, swaps
     unsigned *status;
+    // convergence monitoring (null when off)
+    double *conv_hist;          // [G][Tl][conv_window]: rewritten for the swap step with the costs after the pass
+    uint8_t *conv_swaps;        // [G][conv_window] ring of swap outcomes in the order the reference appends them
+    unsigned long long *conv_swap_total;    // [G] outcomes appended so far
+    int conv_window, swap_frequency;
+};
+
+// One convergence check per ladder (pt_graph_convergence_kernel).
+struct ConvParams {
+    const double *hist;         // chain c of ladder g, sample k (0 = oldest): hist[g*ladder_stride + c*chain_stride + (first + k) % ring]
+    long long ladder_stride, chain_stride;
+    int ring, first, n;         // ring size, ring index of the oldest sample, samples per chain
+    int chains, window, ladders;
+    const uint8_t *swaps;       // [ladders][swap_ring]
+    const unsigned long long *swap_total;   // [ladders] outcomes appended so far, or null: swap_n entries each
+    int swap_ring, swap_n;
+    double strictness;
+    int iteration;
+    pt_convergence_metrics *out;    // [ladders]
 };

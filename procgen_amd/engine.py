@@ -107,6 +107,24 @@ class GraphEngine:
     def set_step(self, step):
         nt.check(self.L.pt_graph_set_step(self.h, step))
 
+    def enable_convergence(self, window_size):
+        """Keep the last `window_size` chain costs and swap outcomes of every ladder on the device."""
+        nt.check(self.L.pt_graph_enable_convergence(self.h, window_size))
+
+    def check_convergence(self, strictness, iteration=0):
+        """Convergence.checkConvergence per ladder: a list of dicts (None for an absent statistic)."""
+        out = (nt.ConvergenceMetrics * self.G)()
+        nt.check(self.L.pt_graph_check_convergence(self.h, float(strictness), int(iteration), C.cast(out, C.c_void_p)))
+        return [m.as_dict() for m in out]
+
+    def run_until_converged(self, max_iterations, check_freq, strictness):
+        """Convergence.runUntilConvergence: (steps run, metrics of the last check per ladder)."""
+        out = (nt.ConvergenceMetrics * self.G)()
+        done = C.c_int64(0)
+        nt.check(self.L.pt_graph_run_until_converged(self.h, int(max_iterations), int(check_freq), float(strictness),
+                                                     C.byref(done), C.cast(out, C.c_void_p)))
+        return done.value, [m.as_dict() for m in out]
+
     def run_to_swap_point(self, max_steps):
         done, due = C.c_int64(0), C.c_int32(0)
         nt.check(self.L.pt_graph_run_to_swap_point(self.h, max_steps, C.byref(done), C.byref(due)))

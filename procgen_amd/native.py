@@ -61,6 +61,7 @@ EXPORTS = [
     "pt_graph_sync", "pt_graph_set_step", "pt_graph_run_to_swap_point", "pt_graph_local_energy_ptr",
     "pt_graph_swap_pass", "pt_graph_read_energies", "pt_graph_download", "pt_graph_replica_slots", "pt_graph_cost_terms",
     "pt_graph_get_stats", "pt_graph_kernel_time", "pt_graph_stream", "pt_graph_info", "pt_debug_canonical_sum",
+    "pt_graph_enable_convergence", "pt_graph_check_convergence", "pt_graph_run_until_converged", "check_convergence_async",
     "pt_geometric_ladder", "pt_swap_frequency", "pt_seed_key",
     "pt_chunk_default_config", "pt_chunk_create", "pt_chunk_destroy", "pt_chunk_upload", "pt_chunk_set_draws",
     "pt_chunk_enable_trace", "pt_chunk_read_trace", "pt_chunk_run", "pt_chunk_sync", "pt_chunk_download",
@@ -78,6 +79,25 @@ class ChunkConfig(C.Structure):
 CHUNK_RES, CHUNK_VOXELS, CHUNK_DRAWS_PER_STEP, CHUNK_TERMS = 32, 32 ** 3, 8, 12
 CHUNK_TERM_NAMES = ["traversability", "geological", "overhang", "erosion", "aesthetics", "caves", "performance",
                     "biomeTransition", "total", "cave_reach", "underground_air", "solid"]
+
+
+class ConvergenceMetrics(C.Structure):
+    """pt_convergence_metrics"""
+    _fields_ = [("gelman_rubin", C.c_double), ("effective_sample_size", C.c_double), ("cost_stabilization", C.c_double),
+                ("swap_acceptance_rate", C.c_double), ("has_gelman_rubin", C.c_int32), ("has_ess", C.c_int32),
+                ("has_converged", C.c_int32), ("iteration", C.c_int32)]
+
+    def as_dict(self):
+        return dict(gelman_rubin=self.gelman_rubin if self.has_gelman_rubin else None,
+                    effective_sample_size=self.effective_sample_size if self.has_ess else None,
+                    cost_stabilization=self.cost_stabilization, swap_acceptance_rate=self.swap_acceptance_rate,
+                    has_converged=bool(self.has_converged), iteration=self.iteration)
+
+
+class LegacyConvergenceMetrics(C.Structure):
+    """The record of the F# extern (reference src/GPU.Compute.fs:88-96)."""
+    _fields_ = [("GelmanRubin", C.c_float), ("EffectiveSampleSize", C.c_float), ("CostStabilization", C.c_float),
+                ("AvgSwapAcceptance", C.c_float), ("Iteration", C.c_int32), ("HasConverged", C.c_int32)]
 
 
 class GraphInfo(C.Structure):
@@ -137,6 +157,11 @@ def load():
     L.pt_graph_stream.restype = vp
     L.pt_graph_stream.argtypes = [vp]
     L.pt_debug_canonical_sum.argtypes = [vp, i64, C.POINTER(dbl), C.POINTER(i32)]
+    L.pt_graph_enable_convergence.argtypes = [vp, i32]
+    L.pt_graph_check_convergence.argtypes = [vp, dbl, i32, vp]
+    L.pt_graph_run_until_converged.argtypes = [vp, i64, i32, dbl, C.POINTER(i64), vp]
+    L.check_convergence_async.restype = None
+    L.check_convergence_async.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, dbl, C.c_int, C.POINTER(LegacyConvergenceMetrics), vp]
     L.collision_detection.restype = None
     L.collision_detection.argtypes = [vp, vp, i32, dbl, vp]
     L.collision_detection_f32.restype = None

@@ -11,6 +11,7 @@ drop-in entry point can be exercised exactly the way that host drives it:
   GPUTempering.optimize           reference GPU.Wrappers.fs:271-344  (one native call per iteration)
   GPUCollision.detect             reference GPU.Wrappers.fs:347-416
   Dispatch.useGPU / optimize      reference GPU.Wrappers.fs:689-724
+  Dispatch.optimizeUntilConvergence  reference GPU.Wrappers.fs:728-753
 
 plus `optimize_batched`, the one-call replacement the reference's glue could switch to.
 Results are (ok, value) / (err, CudaError) pairs standing in for F#'s Result.
@@ -263,3 +264,41 @@ class Dispatch:
         if cpu_run is None:
             raise RuntimeError("GPU path not taken and no CPU ParallelTempering.run supplied")
         return cpu_run(temperatures, graphs, mutate, cost, iterations, 10)
+
+    @classmethod
+    def optimizeUntilConvergence(cls, temperatures, graphs, maxIterations: int, strictness: float,
+                                 onProgress: Optional[Callable] = None, *, node_kind=None, node_value=None,
+                                 edge_capacity: int = 0, seed="libgpu_compute/optimize_until_convergence"):
+        """reference GPU.Wrappers.fs:728-753 over Convergence.runUntilConvergence
+        (ParallelTempering.Core.fs:496-550), with the whole loop on the device: the engine's adaptive
+        mutation and procedural cost take the place of the host's `mutate` and `cost` closures, the
+        swap frequency and the check frequency are the reference's (:740-741).  `onProgress(step,
+        chains, metrics)` is called once, for the check that ended the run (the reference calls it at
+        every check).  Returns (chains, metrics) like the reference."""
+        n, T = len(graphs[0].Nodes), len(temperatures)
+        emax = max(len(g.Edges) for g in graphs)
+        ecap = edge_capacity or max(2 * emax, emax + 64)
+        check_freq = max(50, maxIterations // 20)
+        pos = np.stack([np.asarray(g.Positions, np.float32).reshape(n, 3) for g in graphs])[None]
+        ed = np.zeros((1, T, ecap, 2), np.int32)
+        ec = np.zeros((1, T), np.int32)
+        for i, g in enumerate(graphs):
+            if g.Edges:
+                ed[0, i, :len(g.Edges)] = Marshaling.flattenEdges(g.Edges).reshape(-1, 2)
+            ec[0, i] = len(g.Edges)
+        with GraphEngine(n, ecap, T, 1, seed=seed) as eng:
+            eng.upload(pos, ed, ec, np.asarray(temperatures, np.float64)[None], node_kind, node_value)
+            steps, metrics = eng.run_until_converged(maxIterations, check_freq, strictness)
+            res = eng.download()
+            st = eng.stats()
+        if st["status_bits"]:
+            raise RuntimeError(f"device reported status bits {st['status_bits']:#x}")
+        chains = []
+        for i, g in enumerate(graphs):
+            k = int(res["ecount"][0, i])
+            edges = [(int(a), int(b), 1.0) for a, b in res["edges"][0, i, :k]]
+            chains.append(Chain(SpatialGraph(g.Nodes, res["pos"][0, i], edges), float(res["cost"][0, i]),
+                                float(temperatures[i]), 0.5))
+        if onProgress is not None:
+            onProgress(steps, chains, metrics[0])
+        return chains, metrics[0]

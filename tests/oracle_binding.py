@@ -230,3 +230,42 @@ def run(pos, edges, ecount, kind, value, temps, iters, swap_freq, cfg, *, key=No
     return dict(pos=pos, edges=edges, ecount=ecount, cost=costs, trace=tr,
                 swap_trace=st[:npass.value, :max(T - 1, 0)], err=err,
                 consumed=np.array([streams[t].pos for t in range(T)]), swap_consumed=sw.pos)
+
+
+class ConvMetrics(C.Structure):
+    _fields_ = [("gelman_rubin", C.c_double), ("effective_sample_size", C.c_double), ("cost_stabilization", C.c_double),
+                ("swap_acceptance_rate", C.c_double), ("has_gelman_rubin", C.c_int32), ("has_ess", C.c_int32),
+                ("has_converged", C.c_int32), ("iteration", C.c_int32)]
+
+
+class ConvHistory:
+    """Convergence.ConvergenceHistory with updateHistory / checkConvergence (og_conv_*)."""
+
+    def __init__(self, chains, window):
+        self.L = lib()
+        self.L.og_conv_new.restype = C.c_void_p
+        self.L.og_conv_new.argtypes = [C.c_int, C.c_int]
+        self.L.og_conv_free.argtypes = [C.c_void_p]
+        self.L.og_conv_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        self.L.og_conv_check.argtypes = [C.c_void_p, C.c_int, C.c_double, C.POINTER(ConvMetrics)]
+        self.chains = chains
+        self.h = self.L.og_conv_new(chains, window)
+
+    def update(self, chain_costs, outcomes=()):
+        c = np.ascontiguousarray(chain_costs, np.float64)
+        assert c.size == self.chains
+        o = np.ascontiguousarray(outcomes, np.uint8)
+        self.L.og_conv_update(self.h, c.ctypes.data, o.ctypes.data if o.size else None, int(o.size))
+
+    def check(self, iteration, strictness):
+        m = ConvMetrics()
+        self.L.og_conv_check(self.h, iteration, strictness, C.byref(m))
+        return dict(gelman_rubin=m.gelman_rubin if m.has_gelman_rubin else None,
+                    effective_sample_size=m.effective_sample_size if m.has_ess else None,
+                    cost_stabilization=m.cost_stabilization, swap_acceptance_rate=m.swap_acceptance_rate,
+                    has_converged=bool(m.has_converged), iteration=m.iteration)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.og_conv_free(self.h)
+            self.h = None

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     src = open(os.path.join(ROOT, "include", "procgen_pt.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = set(re.findall(r"\b((?:pt_|parallel_tempering|collision_detection)\w*)\s*\(", src))
+    names = set(re.findall(r"\b((?:pt_|parallel_tempering|collision_detection|check_convergence)\w*)\s*\(", src))
     return sorted(names)
 
 
