@@ -65,6 +65,31 @@ __device__ __forceinline__ fx128 fx_from_double(double t, unsigned &err)
     return r;
 }
 
+// acc += trunc(t * 2^64) for 0 <= t < 2^32, without a branch (the caller vouches for the range).
+__device__ __forceinline__ void fx_add_small_nonneg(fx128 &acc, double t)
+{
+    const double ti = trunc(t);
+    const double p = (t - ti) * 0x1p32;                             // fraction * 2^32, exact
+    const unsigned h32 = __double2uint_rz(p);
+    const unsigned l32 = __double2uint_rz((p - (double)h32) * 0x1p32);
+    const unsigned long long lo = ((unsigned long long)h32 << 32) | (unsigned long long)l32;
+    const unsigned long long l = acc.lo + lo;
+    acc.hi += (long long)(unsigned long long)__double2uint_rz(ti) + (long long)(l < lo);
+    acc.lo = l;
+}
+
+// sqrtf for a normal x well inside the exponent range, correctly rounded: the hardware's
+// approximation (1 ulp) moved to a neighbour when the residual asks for it.
+__device__ __forceinline__ float sqrt_rn_midrange(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rd = fmaf(-sd, s, x), ru = fmaf(-su, s, x);
+    float r = (rd <= 0.0f) ? sd : s;
+    r = (ru > 0.0f) ? su : r;
+    return r;
+}
+
 // nearest double (ties to even) of a * 2^-64
 __device__ __forceinline__ double fx_to_double(fx128 a)
 {

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "pt_graph_kernels.hip.inc"
@@ -36,6 +37,7 @@ struct pt_graph_engine {
     int device = 0, block = 0;
     bool lds_mode = false;
     bool delta_mode = false;    // incremental evaluation (pt_graph_delta_kernel)
+    int ept = 24;               // edges each thread of that kernel holds in registers (24: any workgroup size, 48: at most 512 threads)
     int C = 1;                  // workgroups per replica
     size_t lds_bytes = 0, delta_lds_bytes = 0;
     hipStream_t stream = nullptr;
@@ -117,8 +119,10 @@ int launch_steps(pt_graph_engine *e, long long step0, int nsteps)
         PT_HIP_TRY(hipEventRecord(a, e->stream));
     }
     const dim3 cgrid((unsigned)((e->R + 7) / 8 * 8 * e->C));
-    if (e->delta_mode)
-        hipLaunchKernelGGL(pt_graph_delta_kernel, dim3(e->R), dim3(e->block), e->delta_lds_bytes, e->stream, e->P, step0, nsteps);
+    if (e->delta_mode && e->ept == 48)
+        hipLaunchKernelGGL((pt_graph_delta_kernel<48, 32, 512>), dim3(e->R), dim3(e->block), e->delta_lds_bytes, e->stream, e->P, step0, nsteps);
+    else if (e->delta_mode)
+        hipLaunchKernelGGL((pt_graph_delta_kernel<24, 16, 1024>), dim3(e->R), dim3(e->block), e->delta_lds_bytes, e->stream, e->P, step0, nsteps);
     else if (e->C == 4)
         hipLaunchKernelGGL(pt_graph_cluster_kernel<4>, cgrid, dim3(e->block), e->lds_bytes, e->stream, e->P, step0, nsteps);
     else if (e->C == 3)
@@ -346,8 +350,9 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
 
     // Incremental evaluation: the default whenever its LDS layout fits (positions, parents, five
     // visited sets), the edge list fits the workgroup's registers and no cluster was asked for.
+    e->ept = (block <= 512 && (long long)e->Ecap > 24ll * block) ? 48 : 24;
     if (!(cfg->flags & (PT_FLAG_GLOBAL_MEMORY_PLACEMENT | PT_FLAG_FULL_EVALUATION)) && N < 65535 && cfg->cluster_size <= 1 &&
-        (long long)e->Ecap <= (long long)DELTA_EPT * block) {
+        (long long)e->Ecap <= (long long)e->ept * block) {
         const size_t Npad = ((size_t)N + 3) & ~(size_t)3;
         const size_t need = sizeof(Shared) + Npad * 12 + (((size_t)N * 2 + 15) / 16) * 16 + 5 * ((((size_t)nwords * 4 + 15) / 16) * 16);
         if (need <= LDS_BUDGET) { e->delta_mode = true; e->delta_lds_bytes = need; }
@@ -426,11 +431,13 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         A(e->dparent, sizeof(unsigned short) * (size_t)R * N);
         A(e->dparscr, sizeof(unsigned short) * (size_t)R * N);
         A(e->dlabel, sizeof(unsigned) * (size_t)R * N); A(e->dlabscr, sizeof(unsigned) * (size_t)R * N);
-        A(e->epk, sizeof(unsigned) * (size_t)R * DELTA_EPT * block);
+        A(e->epk, sizeof(unsigned) * (size_t)R * e->ept * block);
     }
     if (herr == hipSuccess) herr = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (herr == hipSuccess && e->delta_mode && e->delta_lds_bytes > 64 * 1024)
-        herr = hipFuncSetAttribute((const void *)pt_graph_delta_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->delta_lds_bytes);
+        herr = hipFuncSetAttribute(e->ept == 48 ? (const void *)pt_graph_delta_kernel<48, 32, 512>
+                                                : (const void *)pt_graph_delta_kernel<24, 16, 1024>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->delta_lds_bytes);
     if (herr == hipSuccess && lds > 64 * 1024) {
         const void *ks[5] = {lds_mode ? (const void *)pt_graph_steps_kernel<true> : (const void *)pt_graph_steps_kernel<false>,
                              lds_mode ? (const void *)pt_graph_init_kernel<true> : (const void *)pt_graph_init_kernel<false>,
@@ -484,7 +491,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     if (e->delta_mode) {
         P.dacc = e->dacc.as<fx128>(); P.dreach = e->dreach.as<int>(); P.dvis = e->dvis.as<unsigned>();
         P.dparent = e->dparent.as<unsigned short>(); P.dparscr = e->dparscr.as<unsigned short>();
-        P.epk = e->epk.as<unsigned>(); P.epk_stride = DELTA_EPT * block;
+        P.epk = e->epk.as<unsigned>(); P.epk_stride = e->ept * block;
         P.dlabel = e->dlabel.as<unsigned>(); P.dlabscr = e->dlabscr.as<unsigned>();
     }
 

@@ -19,7 +19,7 @@ flags = int(a[4]) if len(a) > 4 else 0
 tmin = float(a[5]) if len(a) > 5 else 0.5
 tmax = float(a[6]) if len(a) > 6 else 5.0
 wl = wlm.graph_workload("c2", n, R, 1, t_min=tmin, t_max=tmax)
-eng = GraphEngine(n, wl["ecap"], R, 1, seed="procgen-bench/c2", flags=flags,
+eng = GraphEngine(n, wl["ecap"], R, 1, seed="procgen-bench/c2", flags=flags, block_threads=int(os.environ.get("BLOCK", "0")),
                   mutation_mode=nt.MUT_PERTURB_ONLY if ponly else nt.MUT_ADAPTIVE)
 eng.upload(wl["pos"], wl["edges"], wl["ecount"], wl["temperatures"], wl["kind"], wl["value"])
 eng.run(1 + eng.swap_frequency)
