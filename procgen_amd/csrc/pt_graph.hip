@@ -121,6 +121,8 @@ int launch_steps(pt_graph_engine *e, long long step0, int nsteps)
     const dim3 cgrid((unsigned)((e->R + 7) / 8 * 8 * e->C));
     if (e->delta_mode && e->ept == 48)
         hipLaunchKernelGGL((pt_graph_delta_kernel<48, 32, 512>), dim3(e->R), dim3(e->block), e->delta_lds_bytes, e->stream, e->P, step0, nsteps);
+    else if (e->delta_mode && e->ept == 32)
+        hipLaunchKernelGGL((pt_graph_delta_kernel<32, 16, 768>), dim3(e->R), dim3(e->block), e->delta_lds_bytes, e->stream, e->P, step0, nsteps);
     else if (e->delta_mode)
         hipLaunchKernelGGL((pt_graph_delta_kernel<24, 16, 1024>), dim3(e->R), dim3(e->block), e->delta_lds_bytes, e->stream, e->P, step0, nsteps);
     else if (e->C == 4)
@@ -350,7 +352,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
 
     // Incremental evaluation: the default whenever its LDS layout fits (positions, parents, five
     // visited sets), the edge list fits the workgroup's registers and no cluster was asked for.
-    e->ept = (block <= 512 && (long long)e->Ecap > 24ll * block) ? 48 : 24;
+    e->ept = (block <= 512 && (long long)e->Ecap > 24ll * block) ? 48 : (block <= 768 && (long long)e->Ecap > 24ll * block) ? 32 : 24;
     if (!(cfg->flags & (PT_FLAG_GLOBAL_MEMORY_PLACEMENT | PT_FLAG_FULL_EVALUATION)) && N < 65535 && cfg->cluster_size <= 1 &&
         (long long)e->Ecap <= (long long)e->ept * block) {
         const size_t Npad = ((size_t)N + 3) & ~(size_t)3;
@@ -436,7 +438,8 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     if (herr == hipSuccess) herr = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (herr == hipSuccess && e->delta_mode && e->delta_lds_bytes > 64 * 1024)
         herr = hipFuncSetAttribute(e->ept == 48 ? (const void *)pt_graph_delta_kernel<48, 32, 512>
-                                                : (const void *)pt_graph_delta_kernel<24, 16, 1024>,
+                                   : e->ept == 32 ? (const void *)pt_graph_delta_kernel<32, 16, 768>
+                                                     : (const void *)pt_graph_delta_kernel<24, 16, 1024>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->delta_lds_bytes);
     if (herr == hipSuccess && lds > 64 * 1024) {
         const void *ks[5] = {lds_mode ? (const void *)pt_graph_steps_kernel<true> : (const void *)pt_graph_steps_kernel<false>,

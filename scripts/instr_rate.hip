@@ -1,0 +1,79 @@
+// Issue cost of a few gfx950 vector instructions (diagnostic): one workgroup of W waves on one CU
+// runs a long dependent-free stream of one instruction; cycles per wave-instruction per SIMD follow
+// from s_memtime.  Build: hipcc --offload-arch=gfx950 -O2 -o instr_rate instr_rate.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define REP 64
+#define OUTER 200
+
+template <int OP> __global__ void k(double *out, unsigned long long *cyc, double seed)
+{
+    double a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    float f0 = (float)a0, f1 = f0 + 1, f2 = f0 + 2, f3 = f0 + 3;
+    unsigned u0 = threadIdx.x, u1 = u0 + 1, u2 = u0 + 2, u3 = u0 + 3;
+    unsigned long long q0 = u0, q1 = u1, q2 = u2, q3 = u3;
+    __syncthreads();
+    unsigned long long t0 = clock64();
+    for (int o = 0; o < OUTER; o++) {
+#pragma unroll
+        for (int r = 0; r < REP / 4; r++) {
+            if (OP == 0) { asm volatile("v_add_f64 %0, %0, %1" : "+v"(a0) : "v"(a1)); asm volatile("v_add_f64 %0, %0, %1" : "+v"(a2) : "v"(a3));
+                           asm volatile("v_add_f64 %0, %0, %1" : "+v"(a1) : "v"(a0)); asm volatile("v_add_f64 %0, %0, %1" : "+v"(a3) : "v"(a2)); }
+            if (OP == 1) { asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a0) : "v"(a1)); asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a2) : "v"(a3));
+                           asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a1) : "v"(a0)); asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a3) : "v"(a2)); }
+            if (OP == 2) { asm volatile("v_trunc_f64 %0, %1" : "=v"(a0) : "v"(a1)); asm volatile("v_trunc_f64 %0, %1" : "=v"(a2) : "v"(a3));
+                           asm volatile("v_trunc_f64 %0, %1" : "=v"(a1) : "v"(a0)); asm volatile("v_trunc_f64 %0, %1" : "=v"(a3) : "v"(a2)); }
+            if (OP == 3) { asm volatile("v_cvt_u32_f64 %0, %1" : "=v"(u0) : "v"(a1)); asm volatile("v_cvt_u32_f64 %0, %1" : "=v"(u1) : "v"(a3));
+                           asm volatile("v_cvt_u32_f64 %0, %1" : "=v"(u2) : "v"(a0)); asm volatile("v_cvt_u32_f64 %0, %1" : "=v"(u3) : "v"(a2)); }
+            if (OP == 4) { asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(a0) : "v"(u1)); asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(a2) : "v"(u3));
+                           asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(a1) : "v"(u0)); asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(a3) : "v"(u2)); }
+            if (OP == 5) { asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a0) : "v"(f1)); asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a2) : "v"(f3));
+                           asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a1) : "v"(f0)); asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a3) : "v"(f2)); }
+            if (OP == 6) { asm volatile("v_sqrt_f32 %0, %1" : "=v"(f0) : "v"(f1)); asm volatile("v_sqrt_f32 %0, %1" : "=v"(f2) : "v"(f3));
+                           asm volatile("v_sqrt_f32 %0, %1" : "=v"(f1) : "v"(f0)); asm volatile("v_sqrt_f32 %0, %1" : "=v"(f3) : "v"(f2)); }
+            if (OP == 7) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(f0) : "v"(f1)); asm volatile("v_add_f32 %0, %0, %1" : "+v"(f2) : "v"(f3));
+                           asm volatile("v_add_f32 %0, %0, %1" : "+v"(f1) : "v"(f0)); asm volatile("v_add_f32 %0, %0, %1" : "+v"(f3) : "v"(f2)); }
+            if (OP == 8) { asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(q0) : "v"(u1)); asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(q2) : "v"(u3));
+                           asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(q1) : "v"(u0)); asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(q3) : "v"(u2)); }
+            if (OP == 9) { asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(q0) : "v"(q1)); asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(q2) : "v"(q3));
+                           asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(q1) : "v"(q0)); asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(q3) : "v"(q2)); }
+            if (OP == 10) { asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(a0) : "v"(a1)); asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(a2) : "v"(a3));
+                            asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(a1) : "v"(a0)); asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(a3) : "v"(a2)); }
+            if (OP == 11) { asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a0) : "v"(a1)); asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a2) : "v"(a3));
+                            asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a1) : "v"(a0)); asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a3) : "v"(a2)); }
+            if (OP == 12) { asm volatile("v_cmp_gt_f64 vcc, %0, %1" :: "v"(a0), "v"(a1) : "vcc"); asm volatile("v_cmp_gt_f64 vcc, %0, %1" :: "v"(a2), "v"(a3) : "vcc");
+                            asm volatile("v_cmp_gt_f64 vcc, %0, %1" :: "v"(a1), "v"(a0) : "vcc"); asm volatile("v_cmp_gt_f64 vcc, %0, %1" :: "v"(a3), "v"(a2) : "vcc"); }
+            if (OP == 13) { asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(u0) : "v"(u1)); asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(u2) : "v"(u3));
+                            asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(u1) : "v"(u0)); asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(u3) : "v"(u2)); }
+            if (OP == 14) { asm volatile("v_min_u32 %0, %0, %1" : "+v"(u0) : "v"(u1)); asm volatile("v_min_u32 %0, %0, %1" : "+v"(u2) : "v"(u3));
+                            asm volatile("v_min_u32 %0, %0, %1" : "+v"(u1) : "v"(u0)); asm volatile("v_min_u32 %0, %0, %1" : "+v"(u3) : "v"(u2)); }
+        }
+    }
+    unsigned long long t1 = clock64();
+    if (threadIdx.x == 0) cyc[0] = t1 - t0;
+    out[threadIdx.x] = a0 + a1 + a2 + a3 + f0 + f1 + f2 + f3 + u0 + u1 + u2 + u3 + (double)(q0 + q1 + q2 + q3);
+}
+
+template <int OP> void run(const char *name)
+{
+    double *out; unsigned long long *cyc;
+    hipMalloc(&out, 1024 * 8); hipMalloc(&cyc, 8);
+    for (int waves : {1, 4, 8, 16}) {
+        hipLaunchKernelGGL(k<OP>, dim3(1), dim3(64 * waves), 0, 0, out, cyc, 1.5);
+        hipDeviceSynchronize();
+        unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+        double per_simd = (double)c / ((double)REP * OUTER * ((waves + 3) / 4));
+        std::printf("%-16s waves=%2d  %.2f clock64 ticks per wave-instruction per SIMD\n", name, waves, per_simd);
+    }
+    hipFree(out); hipFree(cyc);
+}
+
+int main()
+{
+    run<7>("v_add_f32"); run<14>("v_min_u32"); run<11>("v_pk_mul_f32"); run<0>("v_add_f64"); run<1>("v_mul_f64"); run<10>("v_fma_f64");
+    run<12>("v_cmp_gt_f64"); run<2>("v_trunc_f64"); run<3>("v_cvt_u32_f64"); run<4>("v_cvt_f64_u32"); run<5>("v_cvt_f64_f32");
+    run<6>("v_sqrt_f32"); run<8>("v_lshlrev_b64"); run<9>("v_lshl_add_u64"); run<13>("v_mov_b32_dpp");
+    return 0;
+}

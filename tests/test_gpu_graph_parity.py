@@ -188,6 +188,21 @@ def _topology_case(name):
         n, T = 64, 3
         wl = wlm.graph_workload("topo-dense", n, T, 1, avg_degree=9.0, edge_headroom=2.0)
         temps = [6.0, 3.0, 1.0]
+    elif name == "hub":             # 150 edges at node 5: more than the incremental kernel's list of incident edges holds
+        n, T = 400, 3
+        wl = wlm.graph_workload("topo-hub", n, T, 1, avg_degree=2.2, edge_headroom=3.0)
+        ec = int(wl["ecount"][0, 0])
+        others = rng.choice(np.arange(6, n), 150, replace=False).astype(np.int32)
+        extra = np.stack([np.where(np.arange(150) % 2 == 0, 5, others), np.where(np.arange(150) % 2 == 0, others, 5)], axis=1)
+        wl["edges"][0, :, ec:ec + 150] = extra
+        wl["ecount"][:] = ec + 150
+        # the hub is what moves most of the time: every replica perturbs, node 5 sits where many draws land
+        temps = [1.5, 1.0, 0.6]
+    elif name == "clump":           # every node within reach of every other: the list of near nodes overflows
+        n, T = 1500, 3
+        wl = wlm.graph_workload("topo-clump", n, T, 1, avg_degree=2.2, edge_headroom=2.0)
+        wl["pos"][:] = (rng.random((n, 3)) * 0.9).astype(np.float32)
+        temps = [1.2, 0.8, 0.5]
     else:
         raise KeyError(name)
     wl["temperatures"][:] = [temps]
@@ -195,7 +210,7 @@ def _topology_case(name):
 
 
 @pytest.mark.parametrize("flags", PLACEMENTS)
-@pytest.mark.parametrize("case", ["near-tree", "fragments", "origin-elsewhere", "duplicates", "dense"])
+@pytest.mark.parametrize("case", ["near-tree", "fragments", "origin-elsewhere", "duplicates", "dense", "hub", "clump"])
 def test_trace_parity_topology_cases(gpu_lib, case, flags):
     wl = _topology_case(case)
     iters, f = 600, 7
@@ -203,10 +218,23 @@ def test_trace_parity_topology_cases(gpu_lib, case, flags):
     orc = pu.oracle_run(wl, iters, f, seed=case)
     pu.assert_same_run(wl, gpu, orc, iters)
     reach = gpu["trace"]["reach0"]
+    if case == "hub":
+        assert ((gpu["trace"]["kind"] == 0) & (gpu["trace"]["a"] == 5)).any(), "the hub was meant to move"
     if case in ("near-tree", "fragments"):
         assert len(np.unique(reach)) > 3, "the case was meant to change the reached set"
     # the tracked cost is a from-scratch evaluation of the final state
     assert np.array_equal(gpu["terms"][0, :, 6], gpu["cost"][0])
+
+
+@pytest.mark.parametrize("block", [512, 768, 1024])
+def test_trace_parity_incremental_kernel_variants(gpu_lib, block):
+    """The incremental kernel holds 24, 32 or 48 edges per thread depending on the workgroup size."""
+    n, T, iters, f = 10500, 4, 160, 7
+    wl = wlm.graph_workload("variants", n, T, 1)
+    assert 24 * 768 < wl["ecap"] <= 32 * 768 and 24 * 512 < wl["ecap"] <= 48 * 512
+    gpu = pu.gpu_run(wl, iters, f, seed="variants", block_threads=block)
+    orc = pu.oracle_run(wl, iters, f, seed="variants", threads=4)
+    pu.assert_same_run(wl, gpu, orc, iters)
 
 
 def test_trace_parity_injected_draws(gpu_lib):
