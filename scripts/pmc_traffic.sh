@@ -22,7 +22,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f)):
         if any(k in r["Kernel_Name"] for k in ("steps_kernel", "delta_kernel", "cluster_kernel")) and r["Counter_Name"] == c:
             agg[r["Dispatch_Id"]] += float(r["Counter_Value"])
-            kernel = r["Kernel_Name"].split("(")[0].split("<")[0]
+            kernel = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").strip()
     last = sorted(agg, key=int)[-1]
     out[c] = agg[last]
 rec = {"kernel": kernel, "fetch_size_kb": out["FETCH_SIZE"], "write_size_kb": out["WRITE_SIZE"],
