@@ -44,7 +44,7 @@ __device__ __forceinline__ fx128 fx_from_double(double t, unsigned &err)
 {
     const double a = fabs(t);
     fx128 r;
-    if (a < 4294967296.0) {
+    if (__builtin_expect(a < 4294967296.0, 1)) {
         const double ti = trunc(a);
         const double s = (a - ti) * 0x1p64;                         // < 2^64, exact
         const unsigned h32 = __double2uint_rz(s * 0x1p-32);
