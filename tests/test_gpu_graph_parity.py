@@ -237,6 +237,15 @@ def test_trace_parity_incremental_kernel_variants(gpu_lib, block):
     pu.assert_same_run(wl, gpu, orc, iters)
 
 
+def test_trace_parity_beyond_16_bit_node_ids(gpu_lib):
+    """70 000 nodes: no LDS placement, no packed 16-bit ids; the shape class of the million-node config."""
+    n, T, iters, f = 70000, 3, 18, 5
+    wl = wlm.graph_workload("wide-ids", n, T, 1)
+    gpu = pu.gpu_run(wl, iters, f, seed="wide-ids")
+    orc = pu.oracle_run(wl, iters, f, seed="wide-ids", threads=3)
+    pu.assert_same_run(wl, gpu, orc, iters)
+
+
 def test_trace_parity_injected_draws(gpu_lib):
     n, T, G, iters, f = 120, 5, 2, 500, 6
     wl = wlm.graph_workload("inject", n, T, G)
