@@ -20,7 +20,7 @@ distinct = min(G, 16)
 wl = wlm.graph_workload("c4", n, T, distinct)
 rep = (G + distinct - 1) // distinct
 tile = lambda x: np.tile(x, (rep,) + (1,) * (x.ndim - 1))[:G]  # noqa: E731
-eng = GraphEngine(n, wl["ecap"], T, G, seed="procgen-bench/c4", flags=flags)
+eng = GraphEngine(n, wl["ecap"], T, G, seed="procgen-bench/c4", flags=flags, block_threads=int(os.environ.get("BLOCK", "0")))
 eng.upload(tile(wl["pos"]), tile(wl["edges"]), tile(wl["ecount"]), tile(wl["temperatures"]), tile(wl["kind"]), tile(wl["value"]))
 eng.run(1 + eng.swap_frequency)
 eng.sync()

@@ -246,6 +246,15 @@ def test_trace_parity_beyond_16_bit_node_ids(gpu_lib):
     pu.assert_same_run(wl, gpu, orc, iters)
 
 
+def test_trace_parity_many_small_replicas(gpu_lib):
+    """More replicas than twice the CUs: the engine then picks its smallest workgroup."""
+    n, T, G, iters, f = 300, 16, 40, 60, 7
+    wl = wlm.graph_workload("many", n, T, G)
+    gpu = pu.gpu_run(wl, iters, f, seed="many")
+    orc = pu.oracle_run(wl, iters, f, seed="many", threads=4)
+    pu.assert_same_run(wl, gpu, orc, iters)
+
+
 def test_trace_parity_injected_draws(gpu_lib):
     n, T, G, iters, f = 120, 5, 2, 500, 6
     wl = wlm.graph_workload("inject", n, T, G)
