@@ -139,6 +139,9 @@ typedef struct pt_graph_config {
  * instead of updating the exact sums incrementally.  Same results bit for bit; a cluster_size
  * above 1 implies it.  Incremental evaluation is the default whenever the replica fits in LDS. */
 #define PT_FLAG_FULL_EVALUATION 2
+/* Incremental evaluation with every array in global memory and 32-bit node ids (what replicas too
+ * large for a CU's LDS get by default); set on a small graph it exists so tests can run that kernel. */
+#define PT_FLAG_STREAMING_INCREMENTAL 4
 
 /* Fill a config with the reference's defaults for N nodes, T temperatures. */
 void pt_graph_default_config(pt_graph_config *cfg, int32_t node_count, int32_t edge_capacity,

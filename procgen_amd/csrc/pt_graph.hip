@@ -11,6 +11,7 @@
 
 #include "pt_graph_kernels.hip.inc"
 #include "pt_graph_delta.hip.inc"
+#include "pt_graph_big.hip.inc"
 
 namespace {
 
@@ -37,6 +38,7 @@ struct pt_graph_engine {
     int device = 0, block = 0;
     bool lds_mode = false;
     bool delta_mode = false;    // incremental evaluation (pt_graph_delta_kernel)
+    bool big_mode = false;      // incremental evaluation in global memory (pt_graph_big_kernel)
     int ept = 24;               // edges each thread of that kernel holds in registers (24: any workgroup size, 48: at most 512 threads)
     int C = 1;                  // workgroups per replica
     size_t lds_bytes = 0, delta_lds_bytes = 0;
@@ -46,6 +48,7 @@ struct pt_graph_engine {
     DevBuf px, py, pz, ea, eb, et, ebuf, ecount, kind, value, origin, terminal, rowend, adj, adj4, cost, temps,
         slot_of_rep, rep_of_slot, cells, sorted, queue, bitmap, collbuf, comm, chain_u, swap_u, trace, swap_trace,
         stats, swap_stats, status, terms, dacc, dreach, dvis, dparent, dparscr, dlabel, dlabscr, epk,
+        dparent32, dparscr32, bvis, bjmp, bdist,
         conv_hist, conv_swaps, conv_swap_total, conv_out;
     int conv_window = 0;            // 0: convergence monitoring off
     long long conv_first_step = 0;  // first step the history holds
@@ -119,7 +122,9 @@ int launch_steps(pt_graph_engine *e, long long step0, int nsteps)
         PT_HIP_TRY(hipEventRecord(a, e->stream));
     }
     const dim3 cgrid((unsigned)((e->R + 7) / 8 * 8 * e->C));
-    if (e->delta_mode && e->ept == 48)
+    if (e->big_mode)
+        hipLaunchKernelGGL(pt_graph_big_kernel, dim3(e->R), dim3(e->block), e->lds_bytes, e->stream, e->P, step0, nsteps);
+    else if (e->delta_mode && e->ept == 48)
         hipLaunchKernelGGL((pt_graph_delta_kernel<48, 32, 512>), dim3(e->R), dim3(e->block), e->delta_lds_bytes, e->stream, e->P, step0, nsteps);
     else if (e->delta_mode && e->ept == 32)
         hipLaunchKernelGGL((pt_graph_delta_kernel<32, 16, 768>), dim3(e->R), dim3(e->block), e->delta_lds_bytes, e->stream, e->P, step0, nsteps);
@@ -336,7 +341,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     int bitmap_in_lds = 0, cells_in_lds = 0;
     int lgx = 0, lgy = 0, lgz = 0;
     bool lds_mode = false;
-    if (!(cfg->flags & PT_FLAG_GLOBAL_MEMORY_PLACEMENT) && N < 65536) {
+    if (!(cfg->flags & (PT_FLAG_GLOBAL_MEMORY_PLACEMENT | PT_FLAG_STREAMING_INCREMENTAL)) && N < 65536) {
         const size_t Npad = ((size_t)N + 3) & ~(size_t)3;
         const size_t fixed = sizeof(Shared) + Npad * 14 + (((size_t)nwords * 4 + 15) / 16) * 16;
         int lmb = mb;
@@ -364,12 +369,18 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     // Incremental evaluation: the default whenever its LDS layout fits (positions, parents, five
     // visited sets), the edge list fits the workgroup's registers and no cluster was asked for.
     e->ept = (block <= 512 && (long long)e->Ecap > 24ll * block) ? 48 : (block <= 768 && (long long)e->Ecap > 24ll * block) ? 32 : 24;
-    if (!(cfg->flags & (PT_FLAG_GLOBAL_MEMORY_PLACEMENT | PT_FLAG_FULL_EVALUATION)) && N < 65535 && cfg->cluster_size <= 1 &&
+    if (!(cfg->flags & (PT_FLAG_GLOBAL_MEMORY_PLACEMENT | PT_FLAG_FULL_EVALUATION | PT_FLAG_STREAMING_INCREMENTAL)) && N < 65535 && cfg->cluster_size <= 1 &&
         (long long)e->Ecap <= (long long)e->ept * block) {
         const size_t Npad = ((size_t)N + 3) & ~(size_t)3;
         const size_t need = sizeof(Shared) + Npad * 12 + (((size_t)N * 2 + 15) / 16) * 16 + 5 * ((((size_t)nwords * 4 + 15) / 16) * 16);
         if (need <= LDS_BUDGET) { e->delta_mode = true; e->delta_lds_bytes = need; }
     }
+
+    // Replicas that got the global placement for their size (or by the streaming flag) are evaluated
+    // incrementally too, by the kernel that keeps everything in global memory.
+    if (!e->delta_mode && !lds_mode && cfg->cluster_size <= 1 &&
+        !(cfg->flags & (PT_FLAG_GLOBAL_MEMORY_PLACEMENT | PT_FLAG_FULL_EVALUATION)))
+        e->big_mode = true;
 
     // Cluster size: as many workgroups per replica (up to 4) as keeps the whole grid co-resident at
     // one workgroup per CU.  Only the LDS-resident placement has a cluster kernel.
@@ -446,6 +457,16 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         A(e->dlabel, sizeof(unsigned) * (size_t)R * N); A(e->dlabscr, sizeof(unsigned) * (size_t)R * N);
         A(e->epk, sizeof(unsigned) * (size_t)R * e->ept * block);
     }
+    if (e->big_mode) {
+        A(e->dacc, sizeof(fx128) * (size_t)R * ACC_COUNT);
+        A(e->dreach, sizeof(int) * (size_t)R * 4);
+        A(e->dvis, sizeof(unsigned) * (size_t)R * 2 * nwords);
+        A(e->dlabel, sizeof(unsigned) * (size_t)R * N); A(e->dlabscr, sizeof(unsigned) * (size_t)R * N);
+        A(e->dparent32, sizeof(unsigned) * (size_t)R * N); A(e->dparscr32, sizeof(unsigned) * (size_t)R * N);
+        A(e->bvis, sizeof(unsigned) * (size_t)R * 3 * nwords);
+        A(e->bjmp, sizeof(unsigned) * (size_t)R * N);
+        A(e->bdist, sizeof(float) * (size_t)R * N);
+    }
     if (herr == hipSuccess) herr = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (herr == hipSuccess && e->delta_mode && e->delta_lds_bytes > 64 * 1024)
         herr = hipFuncSetAttribute(e->ept == 48 ? (const void *)pt_graph_delta_kernel<48, 32, 512>
@@ -460,6 +481,8 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         for (int i = 0; i < (lds_mode ? 5 : 2) && herr == hipSuccess; i++)
             herr = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
+    if (herr == hipSuccess && e->big_mode && lds > 64 * 1024)
+        herr = hipFuncSetAttribute((const void *)pt_graph_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (herr != hipSuccess) {
         int code = herr == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP;
         std::string msg = std::string("engine allocation: ") + hipGetErrorString(herr);
@@ -507,6 +530,13 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         P.dparent = e->dparent.as<unsigned short>(); P.dparscr = e->dparscr.as<unsigned short>();
         P.epk = e->epk.as<unsigned>(); P.epk_stride = e->ept * block;
         P.dlabel = e->dlabel.as<unsigned>(); P.dlabscr = e->dlabscr.as<unsigned>();
+    }
+
+    if (e->big_mode) {
+        P.dacc = e->dacc.as<fx128>(); P.dreach = e->dreach.as<int>(); P.dvis = e->dvis.as<unsigned>();
+        P.dlabel = e->dlabel.as<unsigned>(); P.dlabscr = e->dlabscr.as<unsigned>();
+        P.dparent32 = e->dparent32.as<unsigned>(); P.dparscr32 = e->dparscr32.as<unsigned>();
+        P.bvis = e->bvis.as<unsigned>(); P.bjmp = e->bjmp.as<unsigned>(); P.bdist = e->bdist.as<float>();
     }
 
     SwapParams &S = e->SP;
@@ -937,7 +967,7 @@ int pt_graph_info(pt_graph_engine *e, pt_graph_info_rec *out)
     pt::clear_error();
     if (!e || !out) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null argument");
     std::memset(out, 0, sizeof *out);
-    out->incremental = e->delta_mode ? 1 : 0;
+    out->incremental = (e->delta_mode || e->big_mode) ? 1 : 0;
     out->lds_placement = (e->delta_mode || e->lds_mode) ? 1 : 0;
     out->cluster_size = e->C;
     out->block_threads = e->block;

@@ -79,6 +79,12 @@ struct GraphParams {
     unsigned *dlabscr;          // [R][N]  scratch: labels found while a proposal is evaluated
     unsigned *epk;              // [R][epk_stride]  scratch: the edge list packed as a | b << 16
     int epk_stride;             // edges-per-thread bound times the workgroup size
+    // incremental evaluation with every array in global memory (pt_graph_big_kernel; null otherwise)
+    unsigned *dparent32;        // [R][N]  discovery parents, 32-bit ids
+    unsigned *dparscr32;        // [R][N]  scratch: parents found while a proposal is evaluated
+    unsigned *bvis;             // [R][3][nwords]  scratch visited sets (two searches) and the cut-off subtree
+    unsigned *bjmp;             // [R][N]  scratch of the subtree search
+    float *bdist;               // [R][N]  distances to the proposed centroid between the two distribution passes
     // convergence monitoring (null when off): cost of every chain after every step, a ring per chain
     double *conv_hist;          // [G][Tl][conv_window], step s at index s % conv_window
     int conv_window;

@@ -22,6 +22,7 @@ NODE_ORIGIN, NODE_TERMINAL, NODE_STANDARD = 0, 1, 2
 DRAWS_PER_STEP = 6
 FLAG_GLOBAL_MEMORY_PLACEMENT = 1
 FLAG_FULL_EVALUATION = 2
+FLAG_STREAMING_INCREMENTAL = 4
 
 
 class PtError(RuntimeError):

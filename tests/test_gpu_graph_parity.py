@@ -24,7 +24,8 @@ pytestmark = pytest.mark.gpu
 # incremental evaluation (the default) and both memory placements of the full evaluation must
 # give the same bits
 PLACEMENTS = [pytest.param(0, id="incremental"), pytest.param(nt.FLAG_FULL_EVALUATION, id="full-lds"),
-              pytest.param(nt.FLAG_GLOBAL_MEMORY_PLACEMENT, id="full-global")]
+              pytest.param(nt.FLAG_GLOBAL_MEMORY_PLACEMENT, id="full-global"),
+              pytest.param(nt.FLAG_STREAMING_INCREMENTAL, id="incremental-global")]
 # ... and so must every number of workgroups cooperating on one replica's full evaluation
 CLUSTERS = [pytest.param(c, id=f"cluster{c}") for c in (1, 2, 3, 4)]
 
