@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <type_traits>
@@ -53,6 +54,7 @@ struct pt_graph_engine {
     int conv_window = 0;            // 0: convergence monitoring off
     long long conv_first_step = 0;  // first step the history holds
     long long step = 0;
+    long long steps_since_init = 0, relabel_every = 0;     // incremental kernels: see launch_steps
     long long trace_steps = 0, trace_passes = 0;
     bool uploaded = false;
     std::mutex mu;
@@ -105,9 +107,21 @@ int drain_events(pt_graph_engine *e)
     return PT_OK;
 }
 
+int launch_init(pt_graph_engine *e, const GraphParams &P, int write_cost);
+
 int launch_steps(pt_graph_engine *e, long long step0, int nsteps)
 {
     if (nsteps <= 0) return PT_OK;
+    // The incremental kernels hand out discovery labels from a 32-bit counter that only grows (by at
+    // most one per edge looked at in a step).  Long before it can wrap, the state they continue from is
+    // rebuilt from scratch by the init kernel: same cost, same sums, same reached sets bit for bit, a
+    // fresh search tree with labels below N.
+    if ((e->delta_mode || e->big_mode) && e->steps_since_init > 0 && e->steps_since_init + nsteps > e->relabel_every) {
+        int rc = launch_init(e, e->P, 1);
+        if (rc) return rc;
+        e->steps_since_init = 0;
+    }
+    e->steps_since_init += nsteps;
     hipEvent_t a = nullptr, b = nullptr;
     if (e->timing) {
         if (e->events_used == e->events.size()) {
@@ -382,6 +396,15 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         !(cfg->flags & (PT_FLAG_GLOBAL_MEMORY_PLACEMENT | PT_FLAG_FULL_EVALUATION)))
         e->big_mode = true;
 
+    {
+        // a step raises the counter by at most one per edge (an edge draws a ticket once, when it first
+        // finds its head unvisited) plus one; labels restart below N
+        e->relabel_every = std::max<long long>(1, (3ll << 30) / ((long long)e->Ecap + 2));
+        if (const char *v = std::getenv("PROCGEN_PT_RELABEL_EVERY")) {                   // test hook
+            const long long k = std::atoll(v);
+            if (k > 0) e->relabel_every = k;
+        }
+    }
     // Cluster size: as many workgroups per replica (up to 4) as keeps the whole grid co-resident at
     // one workgroup per CU.  Only the LDS-resident placement has a cluster kernel.
     int C = 1;
@@ -632,6 +655,7 @@ int pt_graph_upload(pt_graph_engine *e, const float *positions, const int32_t *e
     (void)T;
 
     e->step = 0;
+    e->steps_since_init = 0;
     if (e->conv_window) { int rc = enable_convergence(e, e->conv_window); if (rc) return rc; }
     { int rc = launch_init(e, e->P, 1); if (rc) return rc; }
     PT_HIP_TRY(hipStreamSynchronize(st));

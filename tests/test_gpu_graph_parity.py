@@ -247,6 +247,19 @@ def test_trace_parity_beyond_16_bit_node_ids(gpu_lib):
     pu.assert_same_run(wl, gpu, orc, iters)
 
 
+@pytest.mark.parametrize("flags", [0, nt.FLAG_STREAMING_INCREMENTAL], ids=["incremental", "incremental-global"])
+def test_periodic_rebuild_of_the_search_state_changes_nothing(gpu_lib, flags, monkeypatch):
+    """The incremental kernels' state is rebuilt from scratch now and then (their label counter must
+    not wrap); with the rebuild forced every 37 steps the trajectory is still the oracle's."""
+    monkeypatch.setenv("PROCGEN_PT_RELABEL_EVERY", "37")
+    wl = _topology_case("near-tree")
+    iters, f = 500, 7
+    gpu = pu.gpu_run(wl, iters, f, seed="rebuild", chunks=[100, 150, 250], flags=flags)
+    orc = pu.oracle_run(wl, iters, f, seed="rebuild")
+    pu.assert_same_run(wl, gpu, orc, iters)
+    assert len(np.unique(gpu["trace"]["reach0"])) > 3
+
+
 def test_trace_parity_many_small_replicas(gpu_lib):
     """More replicas than twice the CUs: the engine then picks its smallest workgroup."""
     n, T, G, iters, f = 300, 16, 40, 60, 7
