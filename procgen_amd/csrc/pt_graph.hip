@@ -13,6 +13,7 @@
 #include "pt_graph_kernels.hip.inc"
 #include "pt_graph_delta.hip.inc"
 #include "pt_graph_big.hip.inc"
+#include "pt_graph_bigc.hip.inc"
 
 namespace {
 
@@ -40,6 +41,7 @@ struct pt_graph_engine {
     bool lds_mode = false;
     bool delta_mode = false;    // incremental evaluation (pt_graph_delta_kernel)
     bool big_mode = false;      // incremental evaluation in global memory (pt_graph_big_kernel)
+    int CB = 1;                 // ... by that many workgroups per replica (pt_graph_bigc_kernel when > 1)
     int ept = 24;               // edges each thread of that kernel holds in registers (24: any workgroup size, 48: at most 512 threads)
     int C = 1;                  // workgroups per replica
     size_t lds_bytes = 0, delta_lds_bytes = 0;
@@ -49,7 +51,7 @@ struct pt_graph_engine {
     DevBuf px, py, pz, ea, eb, et, ebuf, ecount, kind, value, origin, terminal, rowend, adj, adj4, cost, temps,
         slot_of_rep, rep_of_slot, cells, sorted, queue, bitmap, collbuf, comm, chain_u, swap_u, trace, swap_trace,
         stats, swap_stats, status, terms, dacc, dreach, dvis, dparent, dparscr, dlabel, dlabscr, epk,
-        dparent32, dparscr32, bvis, bjmp, bdist,
+        dparent32, dparscr32, bvis, bjmp, bdist, bcomm,
         conv_hist, conv_swaps, conv_swap_total, conv_out;
     int conv_window = 0;            // 0: convergence monitoring off
     long long conv_first_step = 0;  // first step the history holds
@@ -136,7 +138,11 @@ int launch_steps(pt_graph_engine *e, long long step0, int nsteps)
         PT_HIP_TRY(hipEventRecord(a, e->stream));
     }
     const dim3 cgrid((unsigned)((e->R + 7) / 8 * 8 * e->C));
-    if (e->big_mode)
+    if (e->big_mode && e->CB > 1) {
+        PT_HIP_TRY(hipMemsetAsync(e->bcomm.p, 0, e->bcomm.bytes, e->stream));
+        const unsigned blocks = (unsigned)((e->R + 7) / 8 * 8 * e->CB);
+        hipLaunchKernelGGL(pt_graph_bigc_kernel, dim3(blocks), dim3(e->block), e->lds_bytes, e->stream, e->P, step0, nsteps);
+    } else if (e->big_mode)
         hipLaunchKernelGGL(pt_graph_big_kernel, dim3(e->R), dim3(e->block), e->lds_bytes, e->stream, e->P, step0, nsteps);
     else if (e->delta_mode && e->ept == 48)
         hipLaunchKernelGGL((pt_graph_delta_kernel<48, 32, 512>), dim3(e->R), dim3(e->block), e->delta_lds_bytes, e->stream, e->P, step0, nsteps);
@@ -392,8 +398,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
 
     // Replicas that got the global placement for their size (or by the streaming flag) are evaluated
     // incrementally too, by the kernel that keeps everything in global memory.
-    if (!e->delta_mode && !lds_mode && cfg->cluster_size <= 1 &&
-        !(cfg->flags & (PT_FLAG_GLOBAL_MEMORY_PLACEMENT | PT_FLAG_FULL_EVALUATION)))
+    if (!e->delta_mode && !lds_mode && !(cfg->flags & (PT_FLAG_GLOBAL_MEMORY_PLACEMENT | PT_FLAG_FULL_EVALUATION)))
         e->big_mode = true;
 
     {
@@ -408,7 +413,45 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     // Cluster size: as many workgroups per replica (up to 4) as keeps the whole grid co-resident at
     // one workgroup per CU.  Only the LDS-resident placement has a cluster kernel.
     int C = 1;
-    if (cfg->cluster_size < 0 || cfg->cluster_size > 4) { delete e; return pt::set_error(PT_ERR_INVALID_ARGUMENT, "cluster_size must be 0..4"); }
+    if (cfg->cluster_size < 0 || cfg->cluster_size > (e->big_mode ? 16 : 4)) {
+        delete e;
+        return pt::set_error(PT_ERR_INVALID_ARGUMENT, "cluster_size must be 0..4 (0..16 for replicas held in global memory)");
+    }
+    // a census launch: are `blocks` workgroups with this LDS footprint resident all at once?
+    auto census = [&](unsigned blocks) -> bool {
+        DevBuf probe;
+        unsigned init[2] = {0u, 1u}, res[2] = {0u, 0u};
+        if (probe.alloc(sizeof init) != hipSuccess) { (void)hipGetLastError(); return false; }
+        bool ok = hipMemcpy(probe.p, init, sizeof init, hipMemcpyHostToDevice) == hipSuccess;
+        if (ok && lds > 64 * 1024)
+            ok = hipFuncSetAttribute((const void *)pt_census_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL(pt_census_kernel, dim3(blocks), dim3(64), lds, 0, probe.as<unsigned>(), probe.as<unsigned>() + 1, blocks);
+            ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+                 hipMemcpy(res, probe.p, sizeof res, hipMemcpyDeviceToHost) == hipSuccess;
+        }
+        if (!ok) (void)hipGetLastError();
+        return ok && res[0] == blocks && res[1] == 1u;
+    };
+    if (e->big_mode && cfg->cluster_size != 1) {
+        // Several workgroups per replica pay once a member has tens of thousands of nodes to stream.
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); prop.multiProcessorCount = 0; }
+        const long long rows = ((long long)R + 7) / 8 * 8;
+        int want = cfg->cluster_size;
+        if (want == 0) {
+            want = 1;
+            if (N >= 200000) while (want < 16 && rows * want * 2 <= prop.multiProcessorCount) want *= 2;
+        }
+        while (want > 1 && (rows * want > prop.multiProcessorCount || !census((unsigned)(rows * want)))) {
+            if (cfg->cluster_size > 1) {
+                delete e;
+                return pt::set_error(PT_ERR_INVALID_ARGUMENT, "cluster_size: that many workgroups are not co-resident on this device");
+            }
+            want /= 2;
+        }
+        e->CB = std::max(1, want);
+    }
     if (lds_mode && cfg->cluster_size != 1 && !e->delta_mode) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); prop.multiProcessorCount = 0; }
@@ -489,6 +532,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         A(e->bvis, sizeof(unsigned) * (size_t)R * 3 * nwords);
         A(e->bjmp, sizeof(unsigned) * (size_t)R * N);
         A(e->bdist, sizeof(float) * (size_t)R * N);
+        if (e->CB > 1) A(e->bcomm, sizeof(BigComm) * (size_t)R);
     }
     if (herr == hipSuccess) herr = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (herr == hipSuccess && e->delta_mode && e->delta_lds_bytes > 64 * 1024)
@@ -504,8 +548,11 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         for (int i = 0; i < (lds_mode ? 5 : 2) && herr == hipSuccess; i++)
             herr = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    if (herr == hipSuccess && e->big_mode && lds > 64 * 1024)
+    if (herr == hipSuccess && e->big_mode && lds > 64 * 1024) {
         herr = hipFuncSetAttribute((const void *)pt_graph_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (herr == hipSuccess)
+            herr = hipFuncSetAttribute((const void *)pt_graph_bigc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     if (herr != hipSuccess) {
         int code = herr == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP;
         std::string msg = std::string("engine allocation: ") + hipGetErrorString(herr);
@@ -560,6 +607,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         P.dlabel = e->dlabel.as<unsigned>(); P.dlabscr = e->dlabscr.as<unsigned>();
         P.dparent32 = e->dparent32.as<unsigned>(); P.dparscr32 = e->dparscr32.as<unsigned>();
         P.bvis = e->bvis.as<unsigned>(); P.bjmp = e->bjmp.as<unsigned>(); P.bdist = e->bdist.as<float>();
+        P.CB = e->CB; P.R = e->R; P.bcomm = e->bcomm.as<BigComm>();
     }
 
     SwapParams &S = e->SP;
@@ -993,7 +1041,7 @@ int pt_graph_info(pt_graph_engine *e, pt_graph_info_rec *out)
     std::memset(out, 0, sizeof *out);
     out->incremental = (e->delta_mode || e->big_mode) ? 1 : 0;
     out->lds_placement = (e->delta_mode || e->lds_mode) ? 1 : 0;
-    out->cluster_size = e->C;
+    out->cluster_size = e->big_mode ? e->CB : e->C;
     out->block_threads = e->block;
     out->lds_bytes = (int32_t)(e->delta_mode ? e->delta_lds_bytes : e->lds_bytes);
     out->swap_frequency = e->f;

@@ -25,6 +25,8 @@ struct __align__(128) ClusterComm {
     unsigned long long pad[15];
 };
 
+struct BigComm;
+
 struct GraphParams {
     // sizes
     int N, Ecap, T, G, Tl, slot_base, group_base;
@@ -85,6 +87,8 @@ struct GraphParams {
     unsigned *bvis;             // [R][3][nwords]  scratch visited sets (two searches) and the cut-off subtree
     unsigned *bjmp;             // [R][N]  scratch of the subtree search
     float *bdist;               // [R][N]  distances to the proposed centroid between the two distribution passes
+    int CB, R;                  // pt_graph_bigc_kernel: workgroups per replica; replicas of this engine
+    struct BigComm *bcomm;      // [R] cluster records of that kernel
     // convergence monitoring (null when off): cost of every chain after every step, a ring per chain
     double *conv_hist;          // [G][Tl][conv_window], step s at index s % conv_window
     int conv_window;

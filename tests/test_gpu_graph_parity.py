@@ -269,6 +269,34 @@ def test_trace_parity_many_small_replicas(gpu_lib):
     pu.assert_same_run(wl, gpu, orc, iters)
 
 
+@pytest.mark.parametrize("members", [2, 7, 16])
+@pytest.mark.parametrize("case", ["near-tree", "fragments", "origin-elsewhere", "duplicates", "hub", "clump"])
+def test_trace_parity_streaming_cluster(gpu_lib, case, members):
+    """The global-memory incremental kernel with one replica's loops shared by several workgroups."""
+    wl = _topology_case(case)
+    iters, f = 400, 7
+    gpu = pu.gpu_run(wl, iters, f, seed=case, chunks=[150, 250], flags=nt.FLAG_STREAMING_INCREMENTAL, cluster_size=members)
+    orc = pu.oracle_run(wl, iters, f, seed=case)
+    pu.assert_same_run(wl, gpu, orc, iters)
+    assert np.array_equal(gpu["terms"][0, :, 6], gpu["cost"][0])
+
+
+def test_streaming_cluster_matches_one_workgroup_at_150k_nodes(gpu_lib):
+    """Large enough for every member to stream thousands of nodes: the trace of the clustered kernel
+    equals the single-workgroup kernel's (which the oracle pins at 70 000 nodes)."""
+    n, T, iters, f = 150000, 6, 240, 20
+    wl = wlm.graph_workload("wide-cluster", n, T, 1)
+    one = pu.gpu_run(wl, iters, f, seed="wide-cluster", cluster_size=1)
+    many = pu.gpu_run(wl, iters, f, seed="wide-cluster", cluster_size=16)
+    for k in pu.TRACE_FIELDS:
+        assert np.array_equal(one["trace"][k], many["trace"][k]), k
+    assert np.array_equal(one["swap_trace"], many["swap_trace"])
+    for k in ("cost", "pos", "edges", "ecount"):
+        assert np.array_equal(one[k], many[k]), k
+    assert one["stats"]["status_bits"] == 0 and many["stats"]["status_bits"] == 0
+    assert (one["trace"]["kind"] == 2).any() and len(np.unique(one["trace"]["reach0"])) > 1
+
+
 def test_trace_parity_injected_draws(gpu_lib):
     n, T, G, iters, f = 120, 5, 2, 500, 6
     wl = wlm.graph_workload("inject", n, T, G)
