@@ -281,8 +281,11 @@ def main():
         achieved = bytes_per_prop * props_per_launch / launch_s / 1e9
         valu = flops_per_prop * props_per_launch / launch_s / 1e12
         if info["incremental"]:
-            kernel = "pt_graph_delta_kernel" if info["lds_placement"] else "pt_graph_big_kernel"
+            kernel = ("pt_graph_delta_kernel" if info["lds_placement"]
+                      else "pt_graph_bigc_kernel" if info["cluster_size"] > 1 else "pt_graph_big_kernel")
             how = "incremental exact cost update per proposal (same bits as a full re-evaluation)"
+            if not info["lds_placement"] and info["cluster_size"] > 1:
+                how += f", {info['cluster_size']} workgroups per replica"
         elif info["cluster_size"] > 1:
             kernel, how = "pt_graph_cluster_kernel", f"full cost re-evaluation per proposal by {info['cluster_size']} workgroups per replica"
         else:
