@@ -14,12 +14,14 @@ from procgen_amd.engine import GraphEngine
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("flags", [pytest.param(0, id="incremental"), pytest.param(nt.FLAG_FULL_EVALUATION, id="full")])
+@pytest.mark.parametrize("flags,cluster", [pytest.param(0, 0, id="incremental"), pytest.param(nt.FLAG_FULL_EVALUATION, 0, id="full"),
+                                           pytest.param(nt.FLAG_STREAMING_INCREMENTAL, 1, id="streaming"),
+                                           pytest.param(nt.FLAG_STREAMING_INCREMENTAL, 3, id="streaming-cluster")])
 @pytest.mark.parametrize("n,Tl,parts,iters,f", [(60, 6, 2, 150, 9), (300, 8, 4, 120, 34)])
-def test_split_ladder_matches_whole_ladder(gpu_lib, n, Tl, parts, iters, f, flags):
+def test_split_ladder_matches_whole_ladder(gpu_lib, n, Tl, parts, iters, f, flags, cluster):
     wl = wlm.graph_workload("split-gpu", n, Tl, 1, edge_headroom=3.0, index=n)
     seed = f"split-{n}"
-    whole = pu.gpu_run(wl, iters, f, seed=seed, trace=False, flags=flags)
+    whole = pu.gpu_run(wl, iters, f, seed=seed, trace=False, flags=flags, cluster_size=cluster)
     orc = pu.oracle_run(wl, iters, f, seed=seed, trace=False)
     pu.assert_same_run(wl, whole, orc, iters, trace=False)
 
@@ -27,7 +29,7 @@ def test_split_ladder_matches_whole_ladder(gpu_lib, n, Tl, parts, iters, f, flag
     engines = []
     for p in range(parts):
         eng = GraphEngine(n, wl["ecap"], per, 1, swap_frequency=f, seed=seed, ladder_temp_count=Tl,
-                          ladder_slot_base=p * per, flags=flags)
+                          ladder_slot_base=p * per, flags=flags, cluster_size=cluster)
         lo = p * per
         eng.upload(wl["pos"][:, lo:lo + per], wl["edges"][:, lo:lo + per], wl["ecount"][:, lo:lo + per],
                    wl["temperatures"], wl["kind"], wl["value"])
