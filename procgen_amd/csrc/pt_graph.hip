@@ -355,13 +355,30 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     block = std::min(1024, std::max(64, (block + 63) / 64 * 64));
     e->block = block;
 
+    // Incremental evaluation: the default whenever its LDS layout fits (positions, parents, five
+    // visited sets), the edge list fits the workgroup's registers and no cluster was asked for.
+    e->ept = (block <= 512 && (long long)e->Ecap > 24ll * block) ? 48 : (block <= 768 && (long long)e->Ecap > 24ll * block) ? 32 : 24;
+    if (!(cfg->flags & (PT_FLAG_GLOBAL_MEMORY_PLACEMENT | PT_FLAG_FULL_EVALUATION | PT_FLAG_STREAMING_INCREMENTAL)) && N < 65535 && cfg->cluster_size <= 1 &&
+        (long long)e->Ecap <= (long long)e->ept * block) {
+        const size_t Npad = ((size_t)N + 3) & ~(size_t)3;
+        const size_t need = sizeof(Shared) + Npad * 12 + (((size_t)N * 2 + 15) / 16) * 16 + 5 * ((((size_t)nwords * 4 + 15) / 16) * 16);
+        if (need <= LDS_BUDGET) { e->delta_mode = true; e->delta_lds_bytes = need; }
+    }
+
+    // When the LDS-resident incremental kernel cannot take the replica (too many nodes or edges) and
+    // nothing asks for the full evaluation, the replica goes to global memory and the streaming
+    // incremental kernel: far faster than re-evaluating the whole cost per proposal in LDS.
+    const bool stream = (cfg->flags & PT_FLAG_STREAMING_INCREMENTAL) ||
+                        (!e->delta_mode && cfg->cluster_size <= 1 &&
+                         !(cfg->flags & (PT_FLAG_GLOBAL_MEMORY_PLACEMENT | PT_FLAG_FULL_EVALUATION)));
+
     // Placement.  LDS-resident: positions (8N + 4N), u16 bucket table (2 M'), u16 sorted ids (2N)
     // and the visited bitmap all in LDS; M' is the largest power of two <= M that fits.
     size_t lds = sizeof(Shared);
     int bitmap_in_lds = 0, cells_in_lds = 0;
     int lgx = 0, lgy = 0, lgz = 0;
     bool lds_mode = false;
-    if (!(cfg->flags & (PT_FLAG_GLOBAL_MEMORY_PLACEMENT | PT_FLAG_STREAMING_INCREMENTAL)) && N < 65536) {
+    if (!(cfg->flags & PT_FLAG_GLOBAL_MEMORY_PLACEMENT) && !stream && N < 65536) {
         const size_t Npad = ((size_t)N + 3) & ~(size_t)3;
         const size_t fixed = sizeof(Shared) + Npad * 14 + (((size_t)nwords * 4 + 15) / 16) * 16;
         int lmb = mb;
@@ -385,16 +402,6 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     }
     e->lds_bytes = lds;
     e->lds_mode = lds_mode;
-
-    // Incremental evaluation: the default whenever its LDS layout fits (positions, parents, five
-    // visited sets), the edge list fits the workgroup's registers and no cluster was asked for.
-    e->ept = (block <= 512 && (long long)e->Ecap > 24ll * block) ? 48 : (block <= 768 && (long long)e->Ecap > 24ll * block) ? 32 : 24;
-    if (!(cfg->flags & (PT_FLAG_GLOBAL_MEMORY_PLACEMENT | PT_FLAG_FULL_EVALUATION | PT_FLAG_STREAMING_INCREMENTAL)) && N < 65535 && cfg->cluster_size <= 1 &&
-        (long long)e->Ecap <= (long long)e->ept * block) {
-        const size_t Npad = ((size_t)N + 3) & ~(size_t)3;
-        const size_t need = sizeof(Shared) + Npad * 12 + (((size_t)N * 2 + 15) / 16) * 16 + 5 * ((((size_t)nwords * 4 + 15) / 16) * 16);
-        if (need <= LDS_BUDGET) { e->delta_mode = true; e->delta_lds_bytes = need; }
-    }
 
     // Replicas that got the global placement for their size (or by the streaming flag) are evaluated
     // incrementally too, by the kernel that keeps everything in global memory.
