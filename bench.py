@@ -82,10 +82,10 @@ def cpu_baseline(wl, f):
                                  f"{out['optimised']['seconds']:.1f} s")
 
 
-def measured_traffic(kernel):
+def measured_traffic(kernel, record="pmc_traffic.json"):
     """HBM bytes per launch of the step kernel from the committed PMC passes (rocprofv3 cannot
     run inside this process); None when no measurement of this kernel is on file."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", record)
     try:
         with open(path) as fh:
             rec = json.load(fh)
@@ -179,6 +179,7 @@ def main_chunks():
         per_launch = props / max(klaunch, 1)
         launch_s = kms / max(klaunch, 1) * 1e-3
         achieved = bpp * per_launch / launch_s / 1e9
+        traffic, traffic_note = measured_traffic("pt_chunk_steps_kernel" if G == 4096 else None, "pmc_traffic_chunks.json")
         line = {
             "metric": "Metropolis proposals/sec (whole node), 32^3 voxel chunks x 6 temperatures", "value": props * world / elapsed,
             "unit": "proposals/s", "n_gpus": world, "steps": ARGS.steps, "warmup": ARGS.warmup,
@@ -189,7 +190,8 @@ def main_chunks():
                        "chunks_per_gpu": G, "temperatures": T, "swap_frequency": f,
                        "accept_rate": (st1["accepted"] - st0["accepted"]) / max(props, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "pt_chunk_steps_kernel", "kernel_ms_avg": kms / max(klaunch, 1),
+                         "traffic": traffic, "traffic_note": traffic_note, "kernel": "pt_chunk_steps_kernel",
+                         "kernel_ms_avg": kms / max(klaunch, 1),
                          "launches": klaunch, "proposals_per_launch": per_launch, "algorithmic_bytes_per_proposal": bpp,
                          "algorithmic_note": "bytes one FULL terrain-cost evaluation touches (the reference's work per proposal)"},
         }
@@ -291,7 +293,12 @@ def main():
         else:
             kernel, how = "pt_graph_steps_kernel", "full cost re-evaluation per proposal"
         # the PMC record on file was taken at the headline shape only
-        traffic, traffic_note = measured_traffic(kernel if (n, R, G) == (10000, 64, 1) else None)
+        if (n, R, G) == (10000, 64, 1):
+            traffic, traffic_note = measured_traffic(kernel)
+        elif (n, R, G) == (1000000, 16, 1):
+            traffic, traffic_note = measured_traffic(kernel, "pmc_traffic_1m.json")
+        else:
+            traffic, traffic_note = measured_traffic(None)
         line = {
             "metric": "Metropolis proposals/sec (whole node), 10k-node graph x 64 replicas" if (n, R, G) == (10000, 64, 1)
                       else f"Metropolis proposals/sec (whole node), {n}-node graph x {R * G} replicas",

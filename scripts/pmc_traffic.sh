@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: scripts/pmc_traffic.sh   (run on the GPU box from the repo root)
+#        BENCH_ARGS="--workload chunks" OUT=pmc_traffic_chunks scripts/pmc_traffic.sh   for another workload
 # Two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass) over a short bench run;
 # writes gpurun_out/pmc_traffic.json with the HBM bytes per launch of the step kernel.
 # FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1 KB as rocprofv3 reports them; FETCH_SIZE is doubled
@@ -7,20 +8,22 @@
 set -e
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=${OUT:-pmc_traffic}
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 150 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_$c -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline > $R/gpurun_out/pmc_$c.log 2>&1
+  timeout -s KILL 150 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/${OUT}_$c -- python3 $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline $BENCH_ARGS > $R/gpurun_out/${OUT}_$c.log 2>&1
 done
-python3 - "$R" <<'PY'
+python3 - "$R" "$OUT" <<'PY'
 import csv, collections, glob, json, sys
 R = sys.argv[1]
+OUT = sys.argv[2]
 out = {}
 kernel = None
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(f"{R}/gpurun_out/pmc_{c}/**/*counter_collection.csv", recursive=True)[0]
+    f = glob.glob(f"{R}/gpurun_out/{OUT}_{c}/**/*counter_collection.csv", recursive=True)[0]
     agg = collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
-        if any(k in r["Kernel_Name"] for k in ("steps_kernel", "delta_kernel", "cluster_kernel")) and r["Counter_Name"] == c:
+        if any(k in r["Kernel_Name"] for k in ("steps_kernel", "delta_kernel", "cluster_kernel", "big_kernel", "bigc_kernel")) and r["Counter_Name"] == c:
             agg[r["Dispatch_Id"]] += float(r["Counter_Value"])
             kernel = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").strip()
     last = sorted(agg, key=int)[-1]
@@ -29,6 +32,6 @@ rec = {"kernel": kernel, "fetch_size_kb": out["FETCH_SIZE"], "write_size_kb": ou
        "hbm_bytes_per_launch": 2.0 * out["FETCH_SIZE"] * 1024.0 + out["WRITE_SIZE"] * 1024.0,
        "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes, last launch of bench.py --steps 2; "
                "bytes = 2 x FETCH_SIZE (gfx950 read-request correction) + WRITE_SIZE, KB = 1024 B"}
-json.dump(rec, open(f"{R}/gpurun_out/pmc_traffic.json", "w"), indent=1)
+json.dump(rec, open(f"{R}/gpurun_out/{OUT}.json", "w"), indent=1)
 print(rec)
 PY
