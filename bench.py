@@ -50,6 +50,25 @@ def parse():
     return ap.parse_args()
 
 
+# PROCGEN_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend, to rehearse the N > 1 code path
+# on a one-GPU box (the numbers then mean nothing).
+REHEARSAL = os.environ.get("PROCGEN_BENCH_REHEARSAL") == "1"
+
+
+def init_ranks(torch, dist, world, local_rank):
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if REHEARSAL:
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    return torch.cuda.current_device()
+
+
 def cpu_baseline(wl, f):
     """Time the CPU oracle (a port of the reference's F# path; oracle/) on a bounded sample of
     the same workload: the reference's own algorithms and summation order, one thread per
@@ -131,13 +150,7 @@ def main_chunks():
     import torch
     import torch.distributed as dist
 
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.cuda.current_device()
+    dev = init_ranks(torch, dist, world, local_rank)
     from procgen_amd import workloads as wlm
     from procgen_amd.engine import ChunkEngine
 
@@ -166,7 +179,7 @@ def main_chunks():
     elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if REHEARSAL else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kms, klaunch = eng.kernel_time()
@@ -211,13 +224,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.cuda.current_device()
+    dev = init_ranks(torch, dist, world, local_rank)
 
     import numpy as np
     from procgen_amd import native as nt
@@ -261,7 +268,7 @@ def main():
     barrier()
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if REHEARSAL else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
