@@ -41,7 +41,9 @@ def history_rows(trace, swaps, g, T, f, first_step, last_step):
 
 CONFIGS = [pytest.param(0, 0, id="incremental"), pytest.param(nt.FLAG_FULL_EVALUATION, 0, id="full-lds"),
            pytest.param(nt.FLAG_GLOBAL_MEMORY_PLACEMENT, 0, id="full-global"),
-           pytest.param(nt.FLAG_FULL_EVALUATION, 2, id="cluster2")]
+           pytest.param(nt.FLAG_FULL_EVALUATION, 2, id="cluster2"),
+           pytest.param(nt.FLAG_STREAMING_INCREMENTAL, 1, id="streaming"),
+           pytest.param(nt.FLAG_STREAMING_INCREMENTAL, 3, id="streaming-cluster3")]
 
 
 @pytest.mark.parametrize("flags,cluster", CONFIGS)
