@@ -35,8 +35,8 @@ module Batched =
         val mutable ladder_temp_count: int
         val mutable ladder_slot_base: int
         val mutable block_threads: int
-        val mutable flags: int
-        val mutable cluster_size: int
+        val mutable flags: int               // 0 = defaults (incremental evaluation; placement by size)
+        val mutable cluster_size: int        // 0 = choose
         val mutable reserved: int
 
     [<Struct; StructLayout(LayoutKind.Sequential)>]
