@@ -306,6 +306,22 @@ def main():
             traffic, traffic_note = measured_traffic(kernel, "pmc_traffic_1m.json")
         else:
             traffic, traffic_note = measured_traffic(None)
+        measured_valu = None
+        if (n, R, G) == (10000, 64, 1) and kernel == "pt_graph_delta_kernel":
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_sq.json")) as fh:
+                    sq = json.load(fh)["counters"]
+                lane_instr = sq["SQ_INSTS_VALU"] * 64.0 / launch_s         # VALU lane-instructions per second, this run's launch time
+                # peak issue: one lane-instruction per lane per clock = half the FMA flop peak
+                measured_valu = {"valu_wave_instructions_per_launch": sq["SQ_INSTS_VALU"],
+                                 "salu_wave_instructions_per_launch": sq["SQ_INSTS_SALU"],
+                                 "lds_wave_instructions_per_launch": sq["SQ_INSTS_LDS"],
+                                 "lane_instructions_per_s": lane_instr,
+                                 "frac_of_peak_issue": lane_instr / (FP32_VALU_PEAK_TFLOPS * 1e12 / 2.0),
+                                 "note": "rocprofv3 --pmc SQ_INSTS_* of one launch (profiles/pmc_sq.json) over this run's launch "
+                                         "time; 64 of 256 CUs hold a replica"}
+            except (OSError, ValueError, KeyError):
+                pass
         line = {
             "metric": "Metropolis proposals/sec (whole node), 10k-node graph x 64 replicas" if (n, R, G) == (10000, 64, 1)
                       else f"Metropolis proposals/sec (whole node), {n}-node graph x {R * G} replicas",
@@ -327,7 +343,8 @@ def main():
                                              "proposal); the engine may do less work for the same result",
                          "lds_bytes_per_workgroup": info["lds_bytes"], "block_threads": info["block_threads"],
                          "valu": {"achieved": valu, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": valu / FP32_VALU_PEAK_TFLOPS, "lane_ops_per_proposal": flops_per_prop}},
+                                  "frac": valu / FP32_VALU_PEAK_TFLOPS, "lane_ops_per_proposal": flops_per_prop,
+                                  "measured": measured_valu}},
         }
         if not ARGS.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(wl, f)

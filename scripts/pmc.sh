@@ -16,5 +16,7 @@ for r in csv.DictReader(open(f)):
         agg[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
 last = sorted(agg, key=int)[-1]
 print("dispatch", last, {k: f"{v:.4g}" for k, v in agg[last].items()})
+import json
+json.dump({"dispatch": int(last), "counters": dict(agg[last]), "note": "sums over the last step-kernel dispatch of bench.py --steps 2 (one launch = 12 800 proposals at the headline shape)"}, open(sys.argv[1] + ".json", "w"), indent=1)
 PY
 grep -o '"kernel_ms_avg": [0-9.]*' $R/gpurun_out/$name.log
