@@ -357,7 +357,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
 
     // Incremental evaluation: the default whenever its LDS layout fits (positions, parents, five
     // visited sets), the edge list fits the workgroup's registers and no cluster was asked for.
-    e->ept = (block <= 512 && (long long)e->Ecap > 24ll * block) ? 48 : (block <= 768 && (long long)e->Ecap > 24ll * block) ? 32 : 24;
+    e->ept = (long long)e->Ecap <= 24ll * block ? 24 : (block <= 768 && (long long)e->Ecap <= 32ll * block) ? 32 : block <= 512 ? 48 : 24;
     if (!(cfg->flags & (PT_FLAG_GLOBAL_MEMORY_PLACEMENT | PT_FLAG_FULL_EVALUATION | PT_FLAG_STREAMING_INCREMENTAL)) && N < 65535 && cfg->cluster_size <= 1 &&
         (long long)e->Ecap <= (long long)e->ept * block) {
         const size_t Npad = ((size_t)N + 3) & ~(size_t)3;
