@@ -340,6 +340,10 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         int work = std::max(N, e->Ecap);
         block = 64;
         while (block < 1024 && block * 8 < work) block *= 2;
+        // Twelve waves with 168 registers each run the incremental step faster than sixteen with 128
+        // (10k nodes x 64 replicas: 14.0 against 14.7 us per step) when a replica fits 32 edges and 16
+        // nodes per thread.
+        if (block == 1024 && N <= 16 * 768 && e->Ecap <= 32 * 768) block = 768;
         // Many more replicas than CUs: the device is kept busy by the number of workgroups, and every
         // wave of a workgroup repeats the per-step fixed work, so the smallest workgroup that still
         // holds a replica's edges (24 per thread) and caches its nodes (16 per thread) runs fastest
