@@ -361,7 +361,21 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
 
     // Incremental evaluation: the default whenever its LDS layout fits (positions, parents, five
     // visited sets), the edge list fits the workgroup's registers and no cluster was asked for.
-    e->ept = (long long)e->Ecap <= 24ll * block ? 24 : (block <= 768 && (long long)e->Ecap <= 32ll * block) ? 32 : block <= 512 ? 48 : 24;
+    // Kernel variant (edges per thread / registers per thread): 24 / 128 for workgroups above 768 threads,
+    // 32 / 168 for smaller ones where the list fits -- the larger register budget is what counts (fewer
+    // spills: 14.2 against 15.5 us per step at the headline shape, 117 M against 105 M proposals/s for
+    // 1k-node graphs x 8192 replicas) --, else 48 / 256 (more spills again, the slowest of the three).
+    {
+        const long long cap = e->Ecap;
+        if (block > 768) e->ept = 24;
+        else if (cap <= 32ll * block) e->ept = 32;
+        else if (block <= 512 && cap <= 48ll * block) e->ept = 48;
+        else e->ept = 24;
+        if (const char *v = std::getenv("PROCGEN_PT_EPT")) {        // diagnostic override
+            const int k = std::atoi(v);
+            if ((k == 24 || (k == 32 && block <= 768) || (k == 48 && block <= 512)) && cap <= (long long)k * block) e->ept = k;
+        }
+    }
     if (!(cfg->flags & (PT_FLAG_GLOBAL_MEMORY_PLACEMENT | PT_FLAG_FULL_EVALUATION | PT_FLAG_STREAMING_INCREMENTAL)) && N < 65535 && cfg->cluster_size <= 1 &&
         (long long)e->Ecap <= (long long)e->ept * block) {
         const size_t Npad = ((size_t)N + 3) & ~(size_t)3;
