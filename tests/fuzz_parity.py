@@ -1,0 +1,129 @@
+"""Randomised parity sweep of the spatial-graph engine against the CPU oracle (GPU needed).
+
+Not collected by pytest: run it by hand, `python tests/fuzz_parity.py [cases] [seed]`.  Every case
+draws a graph shape, a layout scale, node roles, a temperature ladder, a move set, cost weights,
+a swap interval, a launch split and one of the engine's kernel routes, runs the job on the GPU
+through the C ABI and on the oracle, and compares the full trace bit for bit.  A failing case
+prints the numbers needed to repeat it.
+"""
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import oracle_binding as ob          # noqa: E402
+import parity_util as pu             # noqa: E402
+from procgen_amd import native as nt      # noqa: E402
+from procgen_amd import workloads as wlm  # noqa: E402
+
+ROUTES = [
+    ("incremental", dict(flags=0)),
+    ("incremental-512", dict(flags=0, block_threads=512)),
+    ("incremental-1024", dict(flags=0, block_threads=1024)),
+    ("full-lds", dict(flags=nt.FLAG_FULL_EVALUATION)),
+    ("full-global", dict(flags=nt.FLAG_GLOBAL_MEMORY_PLACEMENT)),
+    ("incremental-global", dict(flags=nt.FLAG_STREAMING_INCREMENTAL)),
+    ("incremental-global-c3", dict(flags=nt.FLAG_STREAMING_INCREMENTAL, cluster_size=3)),
+    ("full-cluster2", dict(flags=nt.FLAG_FULL_EVALUATION, cluster_size=2)),
+    ("full-cluster4", dict(flags=nt.FLAG_FULL_EVALUATION, cluster_size=4)),
+]
+
+
+def make_case(rng, index):
+    n = int(rng.choice([1, 2, 3, 5, 17, 64, 65, int(rng.integers(6, 400)), int(rng.integers(400, 1500))]))
+    T = int(rng.integers(1, 9))
+    G = int(rng.integers(1, 4))
+    iters = int(rng.integers(20, 350))
+    f = int(rng.choice([1, 2, int(rng.integers(3, 60)), iters + 5]))
+    deg = float(rng.choice([2.0, 2.1, 3.0, 4.0, 8.0]))
+    n_edges = max(int(n * deg / 2.0), n - 1)
+    headroom = 1.0 + (iters + 8) / max(n_edges, 1)
+    wl = wlm.graph_workload("fuzz", n, T, G, layout=str(rng.choice(["box", "sphere"])), avg_degree=deg,
+                            edge_headroom=headroom, index=index)
+    # layout scale: from everything colliding to nothing colliding
+    wl["pos"] *= np.float32(rng.choice([0.2, 0.6, 1.0, 1.7, 4.0]))
+    # edge list surgery: drop a random share (fragments the graph), then maybe repeat a few
+    for g in range(G):
+        ec = int(wl["ecount"][g, 0])
+        e = wl["edges"][g, 0, :ec].copy()
+        mode = rng.integers(0, 4)
+        if mode == 1 and ec:
+            e = e[rng.random(ec) > rng.choice([0.1, 0.5, 0.9])]
+        elif mode == 2:
+            e = e[:0]
+        elif mode == 3 and ec > 4:
+            k = int(rng.integers(1, min(ec, 12)))
+            dup = e[rng.integers(0, ec, size=k)]
+            if rng.random() < 0.5:
+                dup = dup[:, ::-1]
+            e = np.concatenate([e, dup])
+        if len(e) > wl["ecap"] - iters - 1:
+            e = e[:wl["ecap"] - iters - 1]
+        wl["edges"][g, :, :] = 0
+        wl["edges"][g, :, :len(e)] = e
+        wl["ecount"][g, :] = len(e)
+        # node roles: sometimes move the two endpoints, sometimes drop one of them
+        if n >= 3 and rng.random() < 0.5:
+            kind = np.full(n, nt.NODE_STANDARD, np.uint8)
+            a, b = rng.choice(n, 2, replace=False)
+            r = rng.random()
+            if r < 0.8:
+                kind[a] = nt.NODE_ORIGIN
+            if r > 0.1:
+                kind[b] = nt.NODE_TERMINAL
+            wl["kind"][g] = kind
+    # temperatures: the usual ladder, an unsorted one, or one with a very cold replica
+    tm = rng.integers(0, 3)
+    if tm == 1:
+        wl["temperatures"][:] = rng.uniform(0.05, 12.0, size=(G, T))
+    elif tm == 2:
+        wl["temperatures"][:, 0] = 1e-3
+    mutation_mode = int(rng.choice([nt.MUT_ADAPTIVE, nt.MUT_ADAPTIVE, nt.MUT_PERTURB_ONLY]))
+    weights = None if rng.random() < 0.5 else [float(x) for x in rng.uniform(0.0, 2.5, size=6)]
+    cut = int(rng.integers(0, iters + 1))
+    chunks = [c for c in (cut, iters - cut) if c > 0]
+    route = ROUTES[int(rng.integers(0, len(ROUTES)))]
+    return dict(wl=wl, iters=iters, f=f, mutation_mode=mutation_mode, weights=weights, chunks=chunks, route=route,
+                summary=f"n={n} T={T} G={G} iters={iters} f={f} deg={deg} E={wl['ecount'][:, 0].tolist()} "
+                        f"mut={mutation_mode} w={'custom' if weights else 'default'} temps={tm} chunks={chunks} "
+                        f"route={route[0]}")
+
+
+def run_case(case, seed):
+    wl = case["wl"]
+    omut = {nt.MUT_ADAPTIVE: ob.MUT_ADAPTIVE, nt.MUT_PERTURB_ONLY: ob.MUT_PERTURB_ONLY}[case["mutation_mode"]]
+    gpu = pu.gpu_run(wl, case["iters"], case["f"], seed=seed, mutation_mode=case["mutation_mode"],
+                     weights=case["weights"], chunks=case["chunks"], **case["route"][1])
+    orc = pu.oracle_run(wl, case["iters"], case["f"], seed=seed, mutation_mode=omut, weights=case["weights"])
+    pu.assert_same_run(wl, gpu, orc, case["iters"])
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    nt.load()
+    failed = []
+    t0 = time.time()
+    for i in range(cases):
+        rng = np.random.default_rng([seed0, i])
+        case = make_case(rng, seed0 * 100000 + i)
+        try:
+            run_case(case, f"fuzz-{seed0}-{i}")
+        except Exception as exc:                        # noqa: BLE001
+            failed.append(i)
+            print(f"FAIL case {i} (seed {seed0}): {case['summary']}\n  {type(exc).__name__}: {str(exc)[:600]}", flush=True)
+            if not isinstance(exc, AssertionError):
+                traceback.print_exc()
+        if (i + 1) % 20 == 0:
+            print(f"{i + 1} cases, {len(failed)} failed, {time.time() - t0:.0f} s", flush=True)
+    print(f"done: {cases} cases, {len(failed)} failed {failed}", flush=True)
+    return 1 if failed else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
