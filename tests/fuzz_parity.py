@@ -1,6 +1,6 @@
 """Randomised parity sweep of the spatial-graph engine against the CPU oracle (GPU needed).
 
-Not collected by pytest: run it by hand, `python tests/fuzz_parity.py [cases] [seed]`.  Every case
+Not collected by pytest: run it by hand, `python tests/fuzz_parity.py [cases] [seed] [graph|chunk]`.  Every case
 draws a graph shape, a layout scale, node roles, a temperature ladder, a move set, cost weights,
 a swap interval, a launch split and one of the engine's kernel routes, runs the job on the GPU
 through the C ABI and on the oracle, and compares the full trace bit for bit.  A failing case
@@ -103,9 +103,52 @@ def run_case(case, seed):
     pu.assert_same_run(wl, gpu, orc, case["iters"])
 
 
+def make_chunk_case(rng, index):
+    """The voxel-chunk engine's counterpart of make_case: terrain with a random share of air pockets,
+    maybe an opened box around voxel 0 or an all-air / all-solid chunk, fractional densities,
+    a random ladder, weights, swap interval and launch split."""
+    chunks = int(rng.integers(1, 4))
+    T = int(rng.integers(1, 7))
+    iters = int(rng.integers(20, 250))
+    f = int(rng.choice([1, 3, int(rng.integers(4, 60)), iters + 5]))
+    wl = wlm.chunk_workload("fuzz", chunks, T, index=index, air_pockets=float(rng.choice([0.0, 0.03, 0.2, 0.6])))
+    v = np.arange(32 ** 3)
+    x, y, z = v % 32, (v // 32) % 32, v // 1024
+    for g in range(chunks):
+        m = rng.integers(0, 6)
+        if m == 1:
+            a, b, c = rng.integers(2, 20, size=3)
+            wl["density"][g, :, (x < a) & (y < b) & (z < c)] = 0.0
+        elif m == 2:
+            wl["density"][g, :] = 0.0
+        elif m == 3:
+            wl["density"][g, :] = 1.0
+        elif m == 4:                                # fractional densities around the solid threshold
+            pick = rng.random(32 ** 3) < 0.3
+            wl["density"][g, :, pick] = rng.random(int(pick.sum())).astype(np.float32)[:, None]
+    tm = rng.integers(0, 3)
+    if tm == 1:
+        wl["temperatures"][:] = rng.uniform(0.05, 60.0, size=(chunks, T))
+    elif tm == 2:
+        wl["temperatures"][:] = np.sort(rng.uniform(5.0, 50.0, size=(chunks, T)), axis=1)
+    weights = None if rng.random() < 0.5 else [float(w) for w in rng.uniform(0.0, 10.0, size=8)]
+    cut = int(rng.integers(0, iters + 1))
+    return dict(wl=wl, iters=iters, f=f, weights=weights, chunks=[c for c in (cut, iters - cut) if c > 0],
+                summary=f"chunks={chunks} T={T} iters={iters} f={f} temps={tm} w={'custom' if weights else 'default'}")
+
+
+def run_chunk_case(case, seed):
+    import test_gpu_chunk_parity as cp
+    gpu = cp._gpu(case["wl"], case["iters"], case["f"], seed=seed, weights=case["weights"], chunks=case["chunks"])
+    cp._assert_same(case["wl"], gpu, case["iters"], case["f"], seed=seed, weights=case["weights"])
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    if len(sys.argv) > 3 and sys.argv[3] == "chunk":
+        global make_case, run_case
+        make_case, run_case = make_chunk_case, run_chunk_case
     nt.load()
     failed = []
     t0 = time.time()
