@@ -88,18 +88,34 @@ def make_case(rng, index):
     cut = int(rng.integers(0, iters + 1))
     chunks = [c for c in (cut, iters - cut) if c > 0]
     route = ROUTES[int(rng.integers(0, len(ROUTES)))]
+    draws = None
+    if T >= 2 and rng.random() < 0.2:               # injected draws salted with the extreme values
+        passes = (iters + f - 1) // f
+        cu = rng.random((G, T, iters, nt.DRAWS_PER_STEP))
+        su = rng.random((G, passes, T - 1))
+        for arr in (cu, su):
+            salt = rng.random(arr.shape)
+            arr[salt < 0.02] = 0.0
+            arr[(salt >= 0.02) & (salt < 0.04)] = np.nextafter(1.0, 0.0)
+            arr[(salt >= 0.04) & (salt < 0.05)] = 5e-324
+            arr[(salt >= 0.05) & (salt < 0.06)] = 0.5
+        draws = (cu, su)
     return dict(wl=wl, iters=iters, f=f, mutation_mode=mutation_mode, weights=weights, chunks=chunks, route=route,
+                draws=draws,
                 summary=f"n={n} T={T} G={G} iters={iters} f={f} deg={deg} E={wl['ecount'][:, 0].tolist()} "
                         f"mut={mutation_mode} w={'custom' if weights else 'default'} temps={tm} chunks={chunks} "
-                        f"route={route[0]}")
+                        f"route={route[0]} draws={'injected' if draws else 'philox'}")
 
 
 def run_case(case, seed):
     wl = case["wl"]
     omut = {nt.MUT_ADAPTIVE: ob.MUT_ADAPTIVE, nt.MUT_PERTURB_ONLY: ob.MUT_PERTURB_ONLY}[case["mutation_mode"]]
-    gpu = pu.gpu_run(wl, case["iters"], case["f"], seed=seed, mutation_mode=case["mutation_mode"],
-                     weights=case["weights"], chunks=case["chunks"], **case["route"][1])
-    orc = pu.oracle_run(wl, case["iters"], case["f"], seed=seed, mutation_mode=omut, weights=case["weights"])
+    kw = dict(seed=seed)
+    if case.get("draws"):
+        kw = dict(chain_u=case["draws"][0], swap_u=case["draws"][1])
+    gpu = pu.gpu_run(wl, case["iters"], case["f"], mutation_mode=case["mutation_mode"],
+                     weights=case["weights"], chunks=case["chunks"], **case["route"][1], **kw)
+    orc = pu.oracle_run(wl, case["iters"], case["f"], mutation_mode=omut, weights=case["weights"], **kw)
     pu.assert_same_run(wl, gpu, orc, case["iters"])
 
 
