@@ -87,6 +87,8 @@ void parallel_tempering_reset(void);
  * the predicate of the host's CPU routine, reference src/SpatialHash.fs:89-146), written as
  * i0,j0,i1,j1,... sorted by (i, j); out_count[0] = number of pairs.  F# `float` is System.Double, so the
  * unchanged host marshals double*: collision_detection takes doubles, collision_detection_f32 floats.
+ * (The fp32 entry's bound is the fp32 value it receives: a pair whose distance lies between that and the
+ * double the caller rounded it from is judged against the fp32 value.)
  * The host's buffer holds nodeCount * nodeCount / 2 pairs.  On failure the outputs are left untouched
  * (pt_last_error tells why). */
 void collision_detection(const double *positions, int *collision_pairs, int node_count, double min_distance, int *out_count);

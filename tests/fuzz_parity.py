@@ -1,6 +1,6 @@
 """Randomised parity sweep of the spatial-graph engine against the CPU oracle (GPU needed).
 
-Not collected by pytest: run it by hand, `python tests/fuzz_parity.py [cases] [seed] [graph|chunk]`.  Every case
+Not collected by pytest: run it by hand, `python tests/fuzz_parity.py [cases] [seed] [graph|chunk|collide]`.  Every case
 draws a graph shape, a layout scale, node roles, a temperature ladder, a move set, cost weights,
 a swap interval, a launch split and one of the engine's kernel routes, runs the job on the GPU
 through the C ABI and on the oracle, and compares the full trace bit for bit.  A failing case
@@ -159,12 +159,44 @@ def run_chunk_case(case, seed):
     cp._assert_same(case["wl"], gpu, case["iters"], case["f"], seed=seed, weights=case["weights"])
 
 
+def make_collide_case(rng, index):
+    """collision_detection: random clouds with clumps, coincident points, points at the bounds and far offsets."""
+    n = int(rng.choice([0, 1, 2, 3, int(rng.integers(4, 300)), int(rng.integers(300, 6000))]))
+    min_dist = float(rng.choice([0.5, 0.37, 0.05, 1.3, float(rng.uniform(0.002, 3.0))]))
+    spread = min_dist * float(rng.choice([0.8, 2.0, 5.0, 20.0])) * max(n, 1) ** (1.0 / 3.0)
+    pos = ((rng.random((n, 3)) - 0.5) * spread).astype(np.float32)
+    if n >= 8:
+        k = int(rng.integers(1, max(2, n // 4)))
+        src, dst = rng.integers(0, n, size=k), rng.integers(0, n, size=k)
+        jitter = rng.choice([0.0, 0.0005, 0.001, 0.5 * min_dist, min_dist, 1.0001 * min_dist], size=(k, 1))
+        axis = np.eye(3, dtype=np.float64)[rng.integers(0, 3, size=k)]
+        pos[dst] = (pos[src].astype(np.float64) + jitter * axis).astype(np.float32)
+    if rng.random() < 0.3:
+        pos += np.float32(rng.choice([-3.0e3, 1.0e5, 1.0e6]))
+    return dict(pos=pos, min_dist=min_dist, summary=f"n={n} min_dist={min_dist} spread={spread:.3g}")
+
+
+def run_collide_case(case, seed):
+    import test_gpu_collision_detection as cd
+    pos, md = case["pos"], case["min_dist"]
+    want = ob.collision_pairs(pos, md)
+    got, raw = cd._native(pos, md)
+    assert np.array_equal(got, want), f"double-precision entry: {len(got)} pairs vs {len(want)}"
+    assert (raw[2 * len(got):] == -7).all(), "wrote past the reported count"
+    # the single-precision entry receives the bound rounded to fp32: that value is its bound
+    md32 = float(np.float32(md))
+    got32, _ = cd._native(pos, md32, f32=True)
+    assert np.array_equal(got32, ob.collision_pairs(pos, md32)), "single-precision entry differs"
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    global make_case, run_case
     if len(sys.argv) > 3 and sys.argv[3] == "chunk":
-        global make_case, run_case
         make_case, run_case = make_chunk_case, run_chunk_case
+    if len(sys.argv) > 3 and sys.argv[3] == "collide":
+        make_case, run_case = make_collide_case, run_collide_case
     nt.load()
     failed = []
     t0 = time.time()

@@ -25,3 +25,10 @@ def test_random_chunk_case_matches_oracle(gpu_lib, index):
     case = fz.make_chunk_case(np.random.default_rng([SEED, index]), SEED * 100000 + index)
     print(case["summary"])
     fz.run_chunk_case(case, f"fuzz-{SEED}-{index}")
+
+
+@pytest.mark.parametrize("index", range(30))
+def test_random_collision_case_matches_oracle(gpu_lib, index):
+    case = fz.make_collide_case(np.random.default_rng([SEED, index]), index)
+    print(case["summary"])
+    fz.run_collide_case(case, "")
