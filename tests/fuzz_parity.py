@@ -1,6 +1,6 @@
 """Randomised parity sweep of the spatial-graph engine against the CPU oracle (GPU needed).
 
-Not collected by pytest: run it by hand, `python tests/fuzz_parity.py [cases] [seed] [graph|chunk|collide]`.  Every case
+Not collected by pytest: run it by hand, `python tests/fuzz_parity.py [cases] [seed] [graph|chunk|collide|large]`.  Every case
 draws a graph shape, a layout scale, node roles, a temperature ladder, a move set, cost weights,
 a swap interval, a launch split and one of the engine's kernel routes, runs the job on the GPU
 through the C ABI and on the oracle, and compares the full trace bit for bit.  A failing case
@@ -34,19 +34,34 @@ ROUTES = [
 ]
 
 
+LARGE = False                  # graphs beyond what the LDS-resident kernels hold: the global-memory routes
+LARGE_ROUTES = [
+    ("auto", dict(flags=0)),
+    ("incremental-global", dict(flags=nt.FLAG_STREAMING_INCREMENTAL)),
+    ("incremental-global-c2", dict(flags=nt.FLAG_STREAMING_INCREMENTAL, cluster_size=2)),
+    ("incremental-global-c5", dict(flags=nt.FLAG_STREAMING_INCREMENTAL, cluster_size=5)),
+    ("incremental-global-c16", dict(flags=nt.FLAG_STREAMING_INCREMENTAL, cluster_size=16)),
+    ("full-global", dict(flags=nt.FLAG_GLOBAL_MEMORY_PLACEMENT)),
+]
+
+
 def make_case(rng, index):
     n = int(rng.choice([1, 2, 3, 5, 17, 64, 65, int(rng.integers(6, 400)), int(rng.integers(400, 1500))]))
     T = int(rng.integers(1, 9))
     G = int(rng.integers(1, 4))
     iters = int(rng.integers(20, 350))
+    if LARGE:
+        n, T, G, iters = int(rng.integers(14000, 110000)), int(rng.integers(1, 4)), 1, int(rng.integers(20, 70))
     f = int(rng.choice([1, 2, int(rng.integers(3, 60)), iters + 5]))
     deg = float(rng.choice([2.0, 2.1, 3.0, 4.0, 8.0]))
     n_edges = max(int(n * deg / 2.0), n - 1)
     headroom = 1.0 + (iters + 8) / max(n_edges, 1)
-    wl = wlm.graph_workload("fuzz", n, T, G, layout=str(rng.choice(["box", "sphere"])), avg_degree=deg,
-                            edge_headroom=headroom, index=index)
+    layout, scale = str(rng.choice(["box", "sphere"])), float(rng.choice([0.2, 0.6, 1.0, 1.7, 4.0]))
+    if LARGE:                                       # keep the number of colliding pairs linear in n
+        layout, scale = "box", max(scale, 0.6)
+    wl = wlm.graph_workload("fuzz", n, T, G, layout=layout, avg_degree=deg, edge_headroom=headroom, index=index)
     # layout scale: from everything colliding to nothing colliding
-    wl["pos"] *= np.float32(rng.choice([0.2, 0.6, 1.0, 1.7, 4.0]))
+    wl["pos"] *= np.float32(scale)
     # edge list surgery: drop a random share (fragments the graph), then maybe repeat a few
     for g in range(G):
         ec = int(wl["ecount"][g, 0])
@@ -88,6 +103,8 @@ def make_case(rng, index):
     cut = int(rng.integers(0, iters + 1))
     chunks = [c for c in (cut, iters - cut) if c > 0]
     route = ROUTES[int(rng.integers(0, len(ROUTES)))]
+    if LARGE:
+        route = LARGE_ROUTES[int(rng.integers(0, len(LARGE_ROUTES)))]
     draws = None
     if T >= 2 and rng.random() < 0.2:               # injected draws salted with the extreme values
         passes = (iters + f - 1) // f
@@ -195,6 +212,9 @@ def main():
     global make_case, run_case
     if len(sys.argv) > 3 and sys.argv[3] == "chunk":
         make_case, run_case = make_chunk_case, run_chunk_case
+    if len(sys.argv) > 3 and sys.argv[3] == "large":
+        global LARGE
+        LARGE = True
     if len(sys.argv) > 3 and sys.argv[3] == "collide":
         make_case, run_case = make_collide_case, run_collide_case
     nt.load()
@@ -210,7 +230,7 @@ def main():
             print(f"FAIL case {i} (seed {seed0}): {case['summary']}\n  {type(exc).__name__}: {str(exc)[:600]}", flush=True)
             if not isinstance(exc, AssertionError):
                 traceback.print_exc()
-        if (i + 1) % 20 == 0:
+        if (i + 1) % (2 if LARGE else 20) == 0:
             print(f"{i + 1} cases, {len(failed)} failed, {time.time() - t0:.0f} s", flush=True)
     print(f"done: {cases} cases, {len(failed)} failed {failed}", flush=True)
     return 1 if failed else 0
