@@ -179,7 +179,7 @@ int launch_swap(pt_graph_engine *e, long long pass, const double *d_energy)
 {
     SwapParams sp = e->SP;
     sp.energy = d_energy;
-    int threads = 64, blocks = (e->G + threads - 1) / threads;
+    const int threads = PT_WAVE, blocks = e->G;                 // one wave per ladder
     hipLaunchKernelGGL(pt_graph_swap_kernel, dim3(blocks), dim3(threads), 0, e->stream, sp, pass);
     PT_HIP_TRY(hipGetLastError());
     return PT_OK;
