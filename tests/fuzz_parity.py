@@ -1,10 +1,14 @@
-"""Randomised parity sweep of the spatial-graph engine against the CPU oracle (GPU needed).
+"""Randomised parity sweeps of the HIP engines against the CPU oracle (GPU needed).
 
-Not collected by pytest: run it by hand, `python tests/fuzz_parity.py [cases] [seed] [graph|chunk|collide|large]`.  Every case
-draws a graph shape, a layout scale, node roles, a temperature ladder, a move set, cost weights,
-a swap interval, a launch split and one of the engine's kernel routes, runs the job on the GPU
-through the C ABI and on the oracle, and compares the full trace bit for bit.  A failing case
-prints the numbers needed to repeat it.
+Not collected by pytest: run it by hand, `python tests/fuzz_parity.py [cases] [seed] [graph|chunk|collide|large]`.
+  graph    every case draws a graph shape, a layout scale, node roles, a temperature ladder, a move set, cost
+           weights, the draws (Philox, or injected and salted with extreme values), a swap interval, a launch
+           split and one of the engine's kernel routes;
+  large    the same for 14k to 110k nodes through the global-memory routes;
+  chunk    the voxel-chunk engine: air share, opened boxes, uniform chunks, fractional densities, ladders, weights;
+  collide  collision_detection, both entries: clumps, coincident points, points planted at the bounds, far offsets.
+Each case runs on the GPU through the C ABI and on the oracle, and the results (for the engines: the whole
+trace) are compared bit for bit.  A failing case prints the numbers needed to repeat it.
 """
 import os
 import sys
