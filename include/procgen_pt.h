@@ -228,11 +228,13 @@ int pt_graph_replica_slots(pt_graph_engine *e, int32_t *slot_of_replica_all);
 int pt_graph_cost_terms(pt_graph_engine *e, double *terms);
 
 /* Counters since upload: proposals made, accepted, swap attempts, swaps done,
- * status bits (PT_ERR_* seen on device, as a bitmask 1<<code). */
+ * status bits (PT_ERR_* seen on device, as a bitmask 1<<code), and how many removals of a search-tree
+ * edge the incremental kernels rejected from a lower bound of the cost alone (only when no trace is
+ * recorded; the decision is the one the full count gives). */
 typedef struct pt_graph_stats {
     int64_t steps, proposals, accepted, swap_attempts, swaps;
     uint32_t status_bits;
-    uint32_t reserved;
+    uint32_t early_rejects;
 } pt_graph_stats;
 int pt_graph_get_stats(pt_graph_engine *e, pt_graph_stats *out);
 

@@ -1037,7 +1037,12 @@ int pt_graph_get_stats(pt_graph_engine *e, pt_graph_stats *out)
     PT_HIP_TRY(hipMemcpy(&status, e->status.p, sizeof status, hipMemcpyDeviceToHost));
     std::memset(out, 0, sizeof *out);
     out->steps = e->step;
-    for (int r = 0; r < e->R; r++) { out->proposals += (int64_t)st[(size_t)r * 4]; out->accepted += (int64_t)st[(size_t)r * 4 + 1]; }
+    unsigned long long early = 0;
+    for (int r = 0; r < e->R; r++) {
+        out->proposals += (int64_t)st[(size_t)r * 4]; out->accepted += (int64_t)st[(size_t)r * 4 + 1];
+        early += st[(size_t)r * 4 + 2];
+    }
+    out->early_rejects = (uint32_t)std::min<unsigned long long>(early, 0xffffffffull);
     for (int g = 0; g < e->G; g++) { out->swap_attempts += (int64_t)sw[(size_t)g * 2]; out->swaps += (int64_t)sw[(size_t)g * 2 + 1]; }
     out->status_bits = status;
     return PT_OK;

@@ -164,7 +164,8 @@ class GraphEngine:
         s = nt.GraphStats()
         nt.check(self.L.pt_graph_get_stats(self.h, C.byref(s)))
         return dict(steps=s.steps, proposals=s.proposals, accepted=s.accepted,
-                    swap_attempts=s.swap_attempts, swaps=s.swaps, status_bits=s.status_bits)
+                    swap_attempts=s.swap_attempts, swaps=s.swaps, status_bits=s.status_bits,
+                    early_rejects=s.early_rejects)
 
     def info(self):
         i = nt.GraphInfo()

@@ -45,7 +45,7 @@ class GraphConfig(C.Structure):
 class GraphStats(C.Structure):
     _fields_ = [("steps", C.c_int64), ("proposals", C.c_int64), ("accepted", C.c_int64),
                 ("swap_attempts", C.c_int64), ("swaps", C.c_int64), ("status_bits", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("early_rejects", C.c_uint32)]
 
 
 TRACE_DTYPE = np.dtype([("kind", "<i4"), ("a", "<i4"), ("b", "<i4"), ("flags", "<i4"),

@@ -1,11 +1,13 @@
 """Randomised parity sweeps of the HIP engines against the CPU oracle (GPU needed).
 
-Not collected by pytest: run it by hand, `python tests/fuzz_parity.py [cases] [seed] [graph|chunk|collide|large]`.
+Not collected by pytest: run it by hand, `python tests/fuzz_parity.py [cases] [seed] [graph|chunk|collide|large|traceoff]`.
   graph    every case draws a graph shape, a layout scale, node roles, a temperature ladder, a move set, cost
            weights, the draws (Philox, or injected and salted with extreme values), a swap interval, a launch
            split and one of the engine's kernel routes;
   large    the same for 14k to 110k nodes through the global-memory routes;
   chunk    the voxel-chunk engine: air share, opened boxes, uniform chunks, fractional densities, ladders, weights;
+  traceoff sparse graphs on hot ladders with NO step trace recorded (the production paths of the incremental
+           kernels, early rejection of tree-edge removals included): final state, swaps, slot map, counts;
   collide  collision_detection, both entries: clumps, coincident points, points planted at the bounds, far offsets.
 Each case runs on the GPU through the C ABI and on the oracle, and the results (for the engines: the whole
 trace) are compared bit for bit.  A failing case prints the numbers needed to repeat it.
@@ -134,10 +136,48 @@ def run_case(case, seed):
     kw = dict(seed=seed)
     if case.get("draws"):
         kw = dict(chain_u=case["draws"][0], swap_u=case["draws"][1])
+    trace = case.get("trace", True)
     gpu = pu.gpu_run(wl, case["iters"], case["f"], mutation_mode=case["mutation_mode"],
-                     weights=case["weights"], chunks=case["chunks"], **case["route"][1], **kw)
+                     weights=case["weights"], chunks=case["chunks"], trace=trace, **case["route"][1], **kw)
     orc = pu.oracle_run(wl, case["iters"], case["f"], mutation_mode=omut, weights=case["weights"], **kw)
-    pu.assert_same_run(wl, gpu, orc, case["iters"])
+    pu.assert_same_run(wl, gpu, orc, case["iters"], trace=trace)
+    return gpu
+
+
+# Without a step trace the incremental kernels may reject the removal of a search-tree edge from a lower
+# bound of the cost (the node the edge led to is certainly lost) instead of counting everything that is
+# lost with it.  Only runs that record no trace take that path, so it gets a sweep of its own: sparse
+# graphs where most removals cut a tree edge, through the three incremental routes, compared with the
+# oracle on the final state, the swap decisions, the slot map and the accepted / swap counts.
+TRACEOFF_ROUTES = [
+    ("incremental", dict(flags=0)),
+    ("incremental-512", dict(flags=0, block_threads=512)),
+    ("incremental-global", dict(flags=nt.FLAG_STREAMING_INCREMENTAL)),
+    ("incremental-global-c2", dict(flags=nt.FLAG_STREAMING_INCREMENTAL, cluster_size=2)),
+    ("incremental-global-c5", dict(flags=nt.FLAG_STREAMING_INCREMENTAL, cluster_size=5)),
+]
+
+
+def make_traceoff_case(rng, index):
+    n = int(rng.choice([24, 65, int(rng.integers(30, 400)), int(rng.integers(400, 1500))]))
+    T = int(rng.integers(2, 9))
+    G = int(rng.integers(1, 3))
+    iters = int(rng.integers(150, 500))
+    f = int(rng.choice([1, 3, int(rng.integers(4, 60))]))
+    deg = float(rng.choice([2.0, 2.02, 2.06, 2.1]))
+    n_edges = max(int(n * deg / 2.0), n - 1)
+    wl = wlm.graph_workload("fuzz-off", n, T, G, layout="box", avg_degree=deg,
+                            edge_headroom=1.0 + (iters + 8) / max(n_edges, 1), index=index)
+    # hot ladders propose topology moves four times out of five
+    lo, hi = float(rng.choice([0.6, 2.5])), float(rng.choice([6.0, 12.0]))
+    wl["temperatures"][:] = nt.geometric_ladder(lo, hi, T) if T > 1 else [hi]
+    weights = None if rng.random() < 0.6 else [float(x) for x in rng.uniform(0.0, 2.5, size=6)]
+    cut = int(rng.integers(0, iters + 1))
+    route = TRACEOFF_ROUTES[int(rng.integers(0, len(TRACEOFF_ROUTES)))]
+    return dict(wl=wl, iters=iters, f=f, mutation_mode=nt.MUT_ADAPTIVE, weights=weights,
+                chunks=[c for c in (cut, iters - cut) if c > 0], route=route, draws=None, trace=False,
+                summary=f"trace-off n={n} T={T} G={G} iters={iters} f={f} deg={deg} "
+                        f"w={'custom' if weights else 'default'} route={route[0]}")
 
 
 def make_chunk_case(rng, index):
@@ -221,6 +261,13 @@ def main():
         LARGE = True
     if len(sys.argv) > 3 and sys.argv[3] == "collide":
         make_case, run_case = make_collide_case, run_collide_case
+    early = [0]
+    if len(sys.argv) > 3 and sys.argv[3] == "traceoff":
+        graph_case = run_case
+
+        def run_case(case, seed):                        # noqa: F811
+            early[0] += graph_case(case, seed)["stats"]["early_rejects"]
+        make_case = make_traceoff_case
     nt.load()
     failed = []
     t0 = time.time()
@@ -236,6 +283,8 @@ def main():
                 traceback.print_exc()
         if (i + 1) % (2 if LARGE else 20) == 0:
             print(f"{i + 1} cases, {len(failed)} failed, {time.time() - t0:.0f} s", flush=True)
+    if len(sys.argv) > 3 and sys.argv[3] == "traceoff":
+        print(f"removals rejected from the lower bound: {early[0]}", flush=True)
     print(f"done: {cases} cases, {len(failed)} failed {failed}", flush=True)
     return 1 if failed else 0
 

@@ -39,21 +39,35 @@ def gpu_run(wl, iters, swap_freq, *, seed=None, key=0, mutation_mode=nt.MUT_ADAP
         if chain_u is not None:
             eng.set_draws(chain_u, swap_u)
         passes = (iters + swap_freq - 1) // swap_freq if swap_freq > 0 else 0
-        if trace:
-            eng.enable_trace(iters, passes)
+        # without a step trace the swap decisions are still recorded (the step kernels then take the
+        # paths they take in production: no per-step record is written)
+        eng.enable_trace(iters if trace else 0, passes)
         for c in (chunks or [iters]):
             eng.run(c)
         eng.sync()
         res = eng.download()
         res["init_cost"] = init_cost
         res["stats"] = eng.stats()
-        if trace:
-            res["trace"], res["swap_trace"] = eng.read_trace(iters, passes)
+        res["trace"], res["swap_trace"] = eng.read_trace(iters if trace else 0, passes)
         res["terms"] = eng.cost_terms()
         res["slots"] = eng.replica_slots()
         return res
     finally:
         eng.close()
+
+
+def slots_after(swap_trace, T):
+    """slot_of_replica after the recorded swap passes: replica t starts in slot t and an accepted
+    swap of the pair (i, i+1) exchanges the replicas held by those two slots."""
+    rep_of_slot = list(range(T))
+    for row in swap_trace:
+        for i in range(T - 1):
+            if row[i]:
+                rep_of_slot[i], rep_of_slot[i + 1] = rep_of_slot[i + 1], rep_of_slot[i]
+    slot_of_rep = np.zeros(T, np.int32)
+    for s, r in enumerate(rep_of_slot):
+        slot_of_rep[r] = s
+    return slot_of_rep
 
 
 def assert_same_run(wl, gpu, orc, iters, *, trace=True):
@@ -76,10 +90,18 @@ def assert_same_run(wl, gpu, orc, iters, *, trace=True):
                     f"ladder {g}: trace first differs at step {s0} chain {c0} (field {f!r}):\n"
                     f"  fields {TRACE_FIELDS}\n  gpu    {gt[s0, c0]}\n  oracle {o['trace'][s0, c0]}")
             assert np.array_equal(gpu["swap_trace"][:, g, :], o["swap_trace"]), f"ladder {g}: swap decisions differ"
+        else:
+            # no step trace on the GPU side: the oracle's own trace (when it has one) still gives the counts
+            assert np.array_equal(gpu["swap_trace"][:, g, :], o["swap_trace"]), f"ladder {g}: swap decisions differ"
+            assert np.array_equal(gpu["slots"][g], slots_after(o["swap_trace"], T)), f"ladder {g}: slot maps differ"
         assert np.array_equal(gpu["ecount"][g], o["ecount"]), f"ladder {g}: edge counts differ"
         assert np.array_equal(gpu["cost"][g], o["cost"]), f"ladder {g}: costs differ {gpu['cost'][g]} vs {o['cost']}"
         assert np.array_equal(gpu["pos"][g], o["pos"]), f"ladder {g}: positions differ"
         for t in range(T):
             ec = o["ecount"][t]
             assert np.array_equal(gpu["edges"][g, t, :ec], o["edges"][t, :ec]), f"ladder {g} chain {t}: edge lists differ"
+    if all(o["trace"] is not None for o in orc):
+        accepted = sum(int(((o["trace"]["flags"] & 4) != 0).sum()) for o in orc)
+        assert gpu["stats"]["accepted"] == accepted, f"accepted {gpu['stats']['accepted']} vs oracle {accepted}"
+    assert gpu["stats"]["swaps"] == sum(int(o["swap_trace"].sum()) for o in orc)
     assert gpu["stats"]["status_bits"] == 0, f"status bits {gpu['stats']['status_bits']:#x}"

@@ -20,6 +20,23 @@ def test_random_case_matches_oracle(gpu_lib, index):
     fz.run_case(case, f"fuzz-{SEED}-{index}")
 
 
+_early_rejects = []
+
+
+@pytest.mark.parametrize("index", range(24))
+def test_random_case_without_trace_matches_oracle(gpu_lib, index):
+    """The paths a production run takes (no step trace): sparse graphs, hot ladders, incremental routes."""
+    case = fz.make_traceoff_case(np.random.default_rng([SEED + 1, index]), (SEED + 1) * 100000 + index)
+    print(case["summary"])
+    gpu = fz.run_case(case, f"fuzz-off-{SEED}-{index}")
+    _early_rejects.append(gpu["stats"]["early_rejects"])
+
+
+def test_cases_without_trace_took_the_early_rejection(gpu_lib):
+    """The slice above is only worth its name if removals were in fact rejected from the lower bound."""
+    assert len(_early_rejects) == 24 and sum(_early_rejects) > 100, _early_rejects
+
+
 @pytest.mark.parametrize("index", range(10))
 def test_random_chunk_case_matches_oracle(gpu_lib, index):
     case = fz.make_chunk_case(np.random.default_rng([SEED, index]), SEED * 100000 + index)

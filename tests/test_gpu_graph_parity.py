@@ -365,6 +365,19 @@ def test_10k_nodes_short_run_matches_oracle(gpu_lib, flags):
     pu.assert_same_run(wl, gpu, orc, iters)
 
 
+def test_full_size_trajectory_matches_oracle(gpu_lib):
+    """10k nodes x 64 replicas (BASELINE config 2), the benchmark's own route (no step trace) for 402
+    iterations = three swap passes: the final positions, edge lists, costs, swap decisions, slot map
+    and the accepted count of all 64 replicas equal the oracle's, bit for bit."""
+    n, T, iters, f = 10000, 64, 402, 200
+    wl = wlm.graph_workload("c2", n, T, 1)
+    gpu = pu.gpu_run(wl, iters, f, seed="c2-full", trace=False, chunks=[1, 200, 201])
+    orc = pu.oracle_run(wl, iters, f, seed="c2-full", threads=16)
+    pu.assert_same_run(wl, gpu, orc, iters, trace=False)
+    assert gpu["swap_trace"].shape[0] == 3 and gpu["swap_trace"].any()
+    assert np.array_equal(gpu["terms"][0, :, 6], gpu["cost"][0])
+
+
 def test_full_size_properties(gpu_lib):
     """10k nodes x 64 replicas (BASELINE config 2): size-independent checks.  After a run the
     tracked energy of every replica equals a from-scratch re-evaluation of its final state,
