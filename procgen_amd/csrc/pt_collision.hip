@@ -4,6 +4,16 @@
 // set of pairs i < j with  eps < (double)|p_j - p_i| < minDistance,  the distance taken in fp32 as
 // sqrt((dx*dx + dy*dy) + dz*dz) without fused multiply-add.  (The reference's CUDA kernel tests
 // dist^2 < min^2 over all n^2 thread pairs and has no lower guard.)  Pairs come back sorted by (i, j).
+//
+// Everything between the upload of the positions and the download of the pairs runs on the device:
+//   cells    cell coordinates and bucket of every node, bucket sizes (atomics)
+//   scan     bucket sizes -> bucket offsets (one workgroup)
+//   fill     node ids ordered by bucket
+//   count    every node counts its partners j > i over the 27 cells around it
+//   scan     counts -> offsets into the pair list (one workgroup; the last offset is the total)
+//   emit     every node writes its partners at its offset and sorts them: node i's run follows node
+//            i-1's, so the list is in (i, j) order with no sort over the whole list
+// The work arrays are a grow-only set the library allocates on first use.
 #include "pt_device.h"
 #include "pt_host.h"
 #include "../../include/procgen_pt.h"
@@ -11,6 +21,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #pragma clang fp contract(off)
@@ -24,12 +35,36 @@ struct CollParams {
     const float *pos;           // [n][3]
     int *cx;                    // [n][3] cell coordinates
     int *bucket_of;             // [n]
-    int *start;                 // [M + 1] bucket offsets
+    int *start;                 // [M + 1] bucket sizes at [b + 1], then bucket offsets at [b]
+    int *cursor;                // [M]
     int *sorted;                // [n] node ids by bucket
-    int2 *pairs;                // output, or null while counting
-    unsigned long long *count;
-    unsigned long long capacity;
+    unsigned long long *off;    // [n + 1] partner counts at [i + 1], then offsets at [i]; [n] = number of pairs
+    int2 *pairs;                // output
+    unsigned long long capacity;    // pairs the output holds
+    int *count_out;             // min(number of pairs, capacity), or null
 };
+
+// ints of work memory for n nodes and 2^mbits buckets (the off array counts double)
+__host__ __device__ constexpr size_t cd_work_ints(size_t n, size_t M) { return 3 * n + n + (M + 1) + M + n + 2 * (n + 1) + 2; }
+
+int cd_mbits(int n)
+{
+    int mbits = 6;
+    while ((1ll << mbits) < 2ll * n && mbits < 26) mbits++;
+    return mbits;
+}
+
+// carve the work arrays out of one block of ints (8-byte aligned base)
+void cd_carve(CollParams &P, int *base)
+{
+    const size_t n = (size_t)P.n, M = (size_t)1 << P.mbits;
+    P.off = (unsigned long long *)base; base += 2 * (n + 1);
+    P.cx = base; base += 3 * n;
+    P.bucket_of = base; base += n;
+    P.sorted = base; base += n;
+    P.start = base; base += M + 1;
+    P.cursor = base;
+}
 
 __device__ __forceinline__ int cd_bucket(int x, int y, int z, int mbits)
 {
@@ -56,46 +91,124 @@ __global__ void cd_cells_kernel(CollParams P)
     atomicAdd(&P.start[b + 1], 1);
 }
 
-__global__ void cd_fill_kernel(CollParams P, int *cursor)
+// In-place inclusive scan of arr[0 .. len) by one workgroup: thread t owns a contiguous run.  With the
+// sizes stored one place up (arr[0] = 0) the result reads as the exclusive offsets plus the total.
+template <class T>
+__global__ __launch_bounds__(1024) void cd_scan_kernel(T *arr, long long len)
+{
+    __shared__ T wave_tot[17];
+    const int B = blockDim.x, tid = threadIdx.x;
+    const long long chunk = (len + B - 1) / B;
+    const long long beg = min((long long)tid * chunk, len), end = min(beg + chunk, len);
+    T s = 0;
+    for (long long i = beg; i < end; i++) s += arr[i];
+    const int lane = tid & (PT_WAVE - 1), wv = tid / PT_WAVE, nw = (B + PT_WAVE - 1) / PT_WAVE;
+    T inc = s;
+#pragma unroll
+    for (int o = 1; o < PT_WAVE; o <<= 1) {
+        const T up = __shfl_up(inc, o, PT_WAVE);
+        if (lane >= o) inc += up;
+    }
+    if (lane == PT_WAVE - 1) wave_tot[wv] = inc;
+    __syncthreads();
+    if (tid == 0) {
+        T run = 0;
+        for (int w = 0; w < nw; w++) { const T t = wave_tot[w]; wave_tot[w] = run; run += t; }
+    }
+    __syncthreads();
+    T run = wave_tot[wv] + inc - s;
+    for (long long i = beg; i < end; i++) { run += arr[i]; arr[i] = run; }
+}
+
+__global__ void cd_fill_kernel(CollParams P)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n) return;
     const int b = P.bucket_of[i];
-    P.sorted[P.start[b] + atomicAdd(&cursor[b], 1)] = i;
+    P.sorted[P.start[b] + atomicAdd(&P.cursor[b], 1)] = i;
 }
 
-// every node scans the 27 cells around its own; a candidate counts only if it really lies in the cell
-// being scanned (other cells can share the bucket), which also keeps each pair from being seen twice
-__global__ void cd_pairs_kernel(CollParams P)
+// Node i's partners: every node scans the 27 cells around its own; a candidate counts only if it really
+// lies in the cell being scanned (other cells can share the bucket, and the same bucket can come up for
+// two of the 27 cells), which keeps each pair from being seen twice.  visit(j) is called per partner.
+template <class Visit>
+__device__ __forceinline__ void cd_partners(const CollParams &P, int i, Visit visit)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
     const float xi = P.pos[3 * i], yi = P.pos[3 * i + 1], zi = P.pos[3 * i + 2];
     const int cx = P.cx[3 * i], cy = P.cx[3 * i + 1], cz = P.cx[3 * i + 2];
     for (int dz = -1; dz <= 1; dz++) for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
         const int nx = cx + dx, ny = cy + dy, nz = cz + dz;
         const int b = cd_bucket(nx, ny, nz, P.mbits);
-        for (int k = P.start[b]; k < P.start[b + 1]; k++) {
+        const int k1 = P.start[b + 1];
+        for (int k = P.start[b]; k < k1; k++) {
             const int j = P.sorted[k];
             if (j <= i) continue;
             if (P.cx[3 * j] != nx || P.cx[3 * j + 1] != ny || P.cx[3 * j + 2] != nz) continue;
             const float ddx = P.pos[3 * j] - xi, ddy = P.pos[3 * j + 1] - yi, ddz = P.pos[3 * j + 2] - zi;
             float s2 = ddx * ddx + ddy * ddy;
             s2 = s2 + ddz * ddz;
-            if (s2 < P.d2_hi && s2 >= P.d2_lo) {
-                const unsigned long long slot = atomicAdd(P.count, 1ull);
-                if (P.pairs && slot < P.capacity) P.pairs[slot] = make_int2(i, j);
-            }
+            if (s2 < P.d2_hi && s2 >= P.d2_lo) visit(j);
         }
     }
 }
 
-struct Buf {
-    void *p = nullptr;
-    ~Buf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
-    template <class T> T *as() const { return (T *)p; }
-};
+__global__ void cd_count_kernel(CollParams P)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) P.off[0] = 0ull;
+    if (i >= P.n) return;
+    unsigned long long c = 0;
+    cd_partners(P, i, [&](int) { c++; });
+    P.off[i + 1] = c;
+}
+
+// heap sort of the y members of a[0 .. m) (all x members are equal)
+__device__ void cd_sort_run(int2 *a, long long m)
+{
+    auto sift = [&](long long root, long long end) {
+        const int v = a[root].y;
+        for (;;) {
+            long long ch = 2 * root + 1;
+            if (ch >= end) break;
+            if (ch + 1 < end && a[ch + 1].y > a[ch].y) ch++;
+            if (a[ch].y <= v) break;
+            a[root].y = a[ch].y;
+            root = ch;
+        }
+        a[root].y = v;
+    };
+    for (long long k = m / 2 - 1; k >= 0; k--) sift(k, m);
+    for (long long end = m - 1; end > 0; end--) {
+        const int t = a[0].y; a[0].y = a[end].y; a[end].y = t;
+        sift(0, end);
+    }
+}
+
+__global__ void cd_emit_kernel(CollParams P)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && P.count_out) *P.count_out = (int)min(P.off[P.n], P.capacity);
+    if (i >= P.n) return;
+    const unsigned long long at = P.off[i];
+    if (at >= P.capacity || P.off[i + 1] == at) return;
+    // a run cut short by the capacity is sorted first where it was counted in full: the pairs kept are
+    // then the first of the (i, j) order.  That needs the whole run in memory, so such a run (at most
+    // one per call) goes through the slow path: repeated selection of the next smallest partner.
+    const unsigned long long want = P.off[i + 1] - at, room = P.capacity - at;
+    if (want <= room) {
+        unsigned long long k = at;
+        cd_partners(P, i, [&](int j) { P.pairs[k++] = make_int2(i, j); });
+        if (want > 1) cd_sort_run(P.pairs + at, (long long)want);
+    } else {
+        int last = i;
+        for (unsigned long long k = 0; k < room; k++) {
+            int best = 0x7fffffff;
+            cd_partners(P, i, [&](int j) { if (j > last && j < best) best = j; });
+            P.pairs[at + k] = make_int2(i, best);
+            last = best;
+        }
+    }
+}
 
 template <class Pred> float first_float_where(Pred pred)
 {
@@ -109,59 +222,98 @@ template <class Pred> float first_float_where(Pred pred)
     return f;
 }
 
+void cd_thresholds(CollParams &P, double min_distance, double eps)
+{
+    P.inv_cell = 1.0 / (min_distance * (1.0 + 0x1p-20));
+    P.d2_hi = first_float_where([&](float s) { return (double)sqrtf(s) >= min_distance; });
+    P.d2_lo = first_float_where([&](float s) { return (double)sqrtf(s) > eps; });
+}
+
+// the passes up to the pair offsets; P.off[n] then holds the number of pairs
+int cd_launch_count(const CollParams &P, hipStream_t st)
+{
+    const size_t M = (size_t)1 << P.mbits;
+    const int threads = 256, blocks = (P.n + threads - 1) / threads;
+    PT_HIP_TRY(hipMemsetAsync(P.start, 0, sizeof(int) * (2 * M + 1), st));      // start[] and cursor[] are adjacent
+    hipLaunchKernelGGL(cd_cells_kernel, dim3(blocks), dim3(threads), 0, st, P);
+    hipLaunchKernelGGL(cd_scan_kernel<int>, dim3(1), dim3(1024), 0, st, P.start, (long long)(M + 1));
+    hipLaunchKernelGGL(cd_fill_kernel, dim3(blocks), dim3(threads), 0, st, P);
+    hipLaunchKernelGGL(cd_count_kernel, dim3(blocks), dim3(threads), 0, st, P);
+    hipLaunchKernelGGL(cd_scan_kernel<unsigned long long>, dim3(1), dim3(1024), 0, st, P.off, (long long)P.n + 1);
+    PT_HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+int cd_launch_emit(const CollParams &P, hipStream_t st)
+{
+    const int threads = 256, blocks = (P.n + threads - 1) / threads;
+    hipLaunchKernelGGL(cd_emit_kernel, dim3(blocks), dim3(threads), 0, st, P);
+    PT_HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+// ---- work memory of the reference entry points: allocated on first use, grown when a call needs more ----
+struct GrowBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t need(size_t n)
+    {
+        if (n <= bytes) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        const size_t want = n + n / 4;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+};
+struct Workspace {
+    std::mutex mu;
+    int device = -1;
+    GrowBuf pos, work, pairs;
+};
+Workspace g_ws;
+
 // pairs_out holds at most `capacity` pairs; *count receives the true number found
 int detect(const float *pos, int n, double min_distance, double eps, int *pairs_out, long long capacity, long long *count)
 {
     *count = 0;
     if (n < 2) return PT_OK;
     if (pt::device_count() < 1) return pt::set_error(PT_ERR_NO_DEVICE, "no HIP device");
-    int mbits = 6;
-    while ((1ll << mbits) < 2ll * n && mbits < 26) mbits++;
-    const size_t M = (size_t)1 << mbits;
-    Buf dpos, dcx, dbucket, dstart, dcursor, dsorted, dcount, dpairs;
-    PT_HIP_TRY(dpos.alloc(sizeof(float) * 3 * (size_t)n)); PT_HIP_TRY(dcx.alloc(sizeof(int) * 3 * (size_t)n));
-    PT_HIP_TRY(dbucket.alloc(sizeof(int) * (size_t)n)); PT_HIP_TRY(dstart.alloc(sizeof(int) * (M + 1)));
-    PT_HIP_TRY(dcursor.alloc(sizeof(int) * M)); PT_HIP_TRY(dsorted.alloc(sizeof(int) * (size_t)n));
-    PT_HIP_TRY(dcount.alloc(sizeof(unsigned long long)));
-    PT_HIP_TRY(hipMemcpy(dpos.p, pos, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice));
-    PT_HIP_TRY(hipMemset(dstart.p, 0, sizeof(int) * (M + 1)));
-    PT_HIP_TRY(hipMemset(dcursor.p, 0, sizeof(int) * M));
-    PT_HIP_TRY(hipMemset(dcount.p, 0, sizeof(unsigned long long)));
+    std::lock_guard<std::mutex> lock(g_ws.mu);
+    int dev = 0;
+    PT_HIP_TRY(hipGetDevice(&dev));
+    if (dev != g_ws.device) {       // the work memory belongs to the device it was allocated on
+        if (g_ws.device >= 0) {
+            int prev = dev;
+            (void)hipSetDevice(g_ws.device);
+            for (GrowBuf *b : {&g_ws.pos, &g_ws.work, &g_ws.pairs}) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->bytes = 0; }
+            (void)hipSetDevice(prev);
+        }
+        g_ws.device = dev;
+    }
     CollParams P;
     std::memset(&P, 0, sizeof P);
-    P.n = n; P.mbits = mbits;
-    P.inv_cell = 1.0 / (min_distance * (1.0 + 0x1p-20));
-    P.d2_hi = first_float_where([&](float s) { return (double)sqrtf(s) >= min_distance; });
-    P.d2_lo = first_float_where([&](float s) { return (double)sqrtf(s) > eps; });
-    P.pos = dpos.as<float>(); P.cx = dcx.as<int>(); P.bucket_of = dbucket.as<int>(); P.start = dstart.as<int>();
-    P.sorted = dsorted.as<int>(); P.count = dcount.as<unsigned long long>();
-    const int threads = 256, blocks = (n + threads - 1) / threads;
-    hipLaunchKernelGGL(cd_cells_kernel, dim3(blocks), dim3(threads), 0, 0, P);
-    PT_HIP_TRY(hipGetLastError());
-    // bucket offsets: an exclusive scan of M + 1 counters, done on the host (one small round trip)
-    std::vector<int> start(M + 1);
-    PT_HIP_TRY(hipMemcpy(start.data(), dstart.p, sizeof(int) * (M + 1), hipMemcpyDeviceToHost));
-    { int run = 0; for (size_t b = 0; b <= M; b++) { run += start[b]; start[b] = run; } }
-    PT_HIP_TRY(hipMemcpy(dstart.p, start.data(), sizeof(int) * (M + 1), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(cd_fill_kernel, dim3(blocks), dim3(threads), 0, 0, P, dcursor.as<int>());
-    PT_HIP_TRY(hipGetLastError());
-    // first pass counts, second pass writes
-    hipLaunchKernelGGL(cd_pairs_kernel, dim3(blocks), dim3(threads), 0, 0, P);
-    PT_HIP_TRY(hipGetLastError());
+    P.n = n; P.mbits = cd_mbits(n);
+    const size_t M = (size_t)1 << P.mbits;
+    PT_HIP_TRY(g_ws.pos.need(sizeof(float) * 3 * (size_t)n));
+    PT_HIP_TRY(g_ws.work.need(sizeof(int) * cd_work_ints((size_t)n, M)));
+    cd_thresholds(P, min_distance, eps);
+    P.pos = (const float *)g_ws.pos.p;
+    cd_carve(P, (int *)g_ws.work.p);
+    hipStream_t st = nullptr;
+    PT_HIP_TRY(hipMemcpyAsync(g_ws.pos.p, pos, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, st));
+    { int rc = cd_launch_count(P, st); if (rc) return rc; }
     unsigned long long found = 0;
-    PT_HIP_TRY(hipMemcpy(&found, dcount.p, sizeof found, hipMemcpyDeviceToHost));
+    PT_HIP_TRY(hipMemcpyAsync(&found, P.off + n, sizeof found, hipMemcpyDeviceToHost, st));
+    PT_HIP_TRY(hipStreamSynchronize(st));
     *count = (long long)found;
-    if (found == 0 || !pairs_out) return PT_OK;
-    PT_HIP_TRY(dpairs.alloc(sizeof(int2) * (size_t)found));
-    PT_HIP_TRY(hipMemset(dcount.p, 0, sizeof(unsigned long long)));
-    P.pairs = dpairs.as<int2>(); P.capacity = found;
-    hipLaunchKernelGGL(cd_pairs_kernel, dim3(blocks), dim3(threads), 0, 0, P);
-    PT_HIP_TRY(hipGetLastError());
-    std::vector<int2> h((size_t)found);
-    PT_HIP_TRY(hipMemcpy(h.data(), dpairs.p, sizeof(int2) * (size_t)found, hipMemcpyDeviceToHost));
-    std::sort(h.begin(), h.end(), [](const int2 &a, const int2 &b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
-    const long long m = std::min<long long>((long long)found, capacity);
-    for (long long k = 0; k < m; k++) { pairs_out[2 * k] = h[(size_t)k].x; pairs_out[2 * k + 1] = h[(size_t)k].y; }
+    const unsigned long long keep = std::min<unsigned long long>(found, (unsigned long long)std::max<long long>(capacity, 0));
+    if (keep == 0 || !pairs_out) return PT_OK;
+    PT_HIP_TRY(g_ws.pairs.need(sizeof(int2) * (size_t)keep));
+    P.pairs = (int2 *)g_ws.pairs.p; P.capacity = keep; P.count_out = nullptr;
+    { int rc = cd_launch_emit(P, st); if (rc) return rc; }
+    PT_HIP_TRY(hipMemcpyAsync(pairs_out, g_ws.pairs.p, sizeof(int2) * (size_t)keep, hipMemcpyDeviceToHost, st));
+    PT_HIP_TRY(hipStreamSynchronize(st));
     return PT_OK;
 }
 

@@ -34,6 +34,8 @@ def test_random_case_without_trace_matches_oracle(gpu_lib, index):
 
 def test_cases_without_trace_took_the_early_rejection(gpu_lib):
     """The slice above is only worth its name if removals were in fact rejected from the lower bound."""
+    if not _early_rejects:
+        pytest.skip("the trace-off cases were deselected")
     assert len(_early_rejects) == 24 and sum(_early_rejects) > 100, _early_rejects
 
 
