@@ -94,6 +94,23 @@ void parallel_tempering_reset(void);
 void collision_detection(const double *positions, int *collision_pairs, int node_count, double min_distance, int *out_count);
 void collision_detection_f32(const float *positions, int *collision_pairs, int node_count, float min_distance, int *out_count);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc): the same pair search as
+ * collision_detection_f32 on arrays already on the device, with all work memory in a fixed array that
+ * is part of the library's device image (about 1.4 MB per GPU, held until the process ends).  It calls
+ * no hipMalloc / hipFree; the first call on a GPU looks that array's address up once.
+ *   d_positions   [node_count][3] float, device
+ *   d_pairs       [pair_capacity][2] int, device: the first min(found, pair_capacity) pairs of the
+ *                 (i, j) order
+ *   d_count       one int, device: min(found, pair_capacity)
+ *   stream        a hipStream_t (NULL: the default stream); the call returns once the work is queued
+ * node_count above PT_COLLISION_DEVICE_MAX_NODES is refused with PT_ERR_INVALID_ARGUMENT.
+ * All calls on one GPU share the work array: calls that overlap in time on one GPU (two streams, two
+ * threads) race; queue them on one stream or order them with events. */
+#define PT_COLLISION_DEVICE_MAX_NODES 32768
+int pt_collision_detect_device(const float *d_positions, int node_count, float min_distance, int *d_pairs,
+                               long long pair_capacity, int *d_count, void *stream);
+
 /* ---- batched spatial-graph engine --------------------------------------- */
 
 typedef struct pt_graph_engine pt_graph_engine;

@@ -13,7 +13,8 @@
 //   scan     counts -> offsets into the pair list (one workgroup; the last offset is the total)
 //   emit     every node writes its partners at its offset and sorts them: node i's run follows node
 //            i-1's, so the list is in (i, j) order with no sort over the whole list
-// The work arrays are a grow-only set the library allocates on first use.
+// The work arrays are either a grow-only set the library allocates (the reference entry points) or a
+// fixed array in device memory (pt_collision_detect_device, which allocates nothing).
 #include "pt_device.h"
 #include "pt_host.h"
 #include "../../include/procgen_pt.h"
@@ -335,6 +336,38 @@ void entry(const Real *positions, int *collision_pairs, int node_count, Real min
     *out_count = (int)std::min<long long>(found, capacity);
 }
 
+// ---- work memory of pt_collision_detect_device: a fixed array in device memory, one copy per GPU ----
+constexpr int NOALLOC_MAX_NODES = PT_COLLISION_DEVICE_MAX_NODES;
+constexpr size_t NOALLOC_MAX_BUCKETS = (size_t)2 * NOALLOC_MAX_NODES;      // cd_mbits(max nodes) buckets
+constexpr size_t NOALLOC_INTS = cd_work_ints(NOALLOC_MAX_NODES, NOALLOC_MAX_BUCKETS);
+static_assert((NOALLOC_MAX_NODES & (NOALLOC_MAX_NODES - 1)) == 0, "the bucket bound assumes a power of two");
+
+}  // namespace
+
+static __device__ __align__(256) int scratch[NOALLOC_INTS];
+
+namespace {
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+int *g_scratch_ptr[MAX_DEVICES];        // device address of `scratch` on each GPU, looked up once per GPU
+
+// The name `scratch` is a host-side handle, not an address a kernel can use: the device address of
+// this GPU's copy comes from the runtime.
+int scratch_address(int dev, int **out)
+{
+    if (dev < 0 || dev >= MAX_DEVICES) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        int *p = nullptr;
+        PT_HIP_TRY(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+        if (!p) return pt::set_error(PT_ERR_HIP, "hipGetSymbolAddress returned a null address");
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return PT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -347,6 +380,37 @@ void collision_detection(const double *positions, int *collision_pairs, int node
 void collision_detection_f32(const float *positions, int *collision_pairs, int node_count, float min_distance, int *out_count)
 {
     entry<float>(positions, collision_pairs, node_count, min_distance, out_count);
+}
+
+int pt_collision_detect_device(const float *d_positions, int node_count, float min_distance, int *d_pairs,
+                               long long pair_capacity, int *d_count, void *stream)
+{
+    pt::clear_error();
+    if (!d_positions || !d_count || node_count < 0 || pair_capacity < 0 || (pair_capacity > 0 && !d_pairs))
+        return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null pointer or negative size");
+    if (node_count > NOALLOC_MAX_NODES)
+        return pt::set_error(PT_ERR_INVALID_ARGUMENT, "pt_collision_detect_device holds at most " + std::to_string(NOALLOC_MAX_NODES) +
+                                                       " nodes in its fixed work memory; use collision_detection for more");
+    if (!(min_distance > 0) || !std::isfinite((double)min_distance))
+        return pt::set_error(PT_ERR_INVALID_ARGUMENT, "minDistance must be positive and finite");
+    hipStream_t st = (hipStream_t)stream;
+    if (node_count < 2) {
+        PT_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(int), st));
+        return PT_OK;
+    }
+    int dev = 0;
+    PT_HIP_TRY(hipGetDevice(&dev));
+    int *work = nullptr;
+    { int rc = scratch_address(dev, &work); if (rc) return rc; }
+    CollParams P;
+    std::memset(&P, 0, sizeof P);
+    P.n = node_count; P.mbits = cd_mbits(node_count);
+    cd_thresholds(P, (double)min_distance, 0.001);
+    P.pos = d_positions;
+    cd_carve(P, work);
+    P.pairs = (int2 *)d_pairs; P.capacity = (unsigned long long)pair_capacity; P.count_out = d_count;
+    { int rc = cd_launch_count(P, st); if (rc) return rc; }
+    return cd_launch_emit(P, st);
 }
 
 }  // extern "C"

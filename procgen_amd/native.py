@@ -56,7 +56,7 @@ TRACE_DTYPE = np.dtype([("kind", "<i4"), ("a", "<i4"), ("b", "<i4"), ("flags", "
 EXPORTS = [
     "pt_last_error", "pt_last_error_string",
     "parallel_tempering_step", "parallel_tempering_step_f32", "parallel_tempering_reset",
-    "collision_detection", "collision_detection_f32",
+    "collision_detection", "collision_detection_f32", "pt_collision_detect_device",
     "pt_graph_default_config", "pt_graph_create", "pt_graph_destroy", "pt_graph_upload",
     "pt_graph_set_draws", "pt_graph_enable_trace", "pt_graph_read_trace", "pt_graph_run",
     "pt_graph_sync", "pt_graph_set_step", "pt_graph_run_to_swap_point", "pt_graph_local_energy_ptr",
@@ -167,6 +167,7 @@ def load():
     L.collision_detection.argtypes = [vp, vp, i32, dbl, vp]
     L.collision_detection_f32.restype = None
     L.collision_detection_f32.argtypes = [vp, vp, i32, C.c_float, vp]
+    L.pt_collision_detect_device.argtypes = [vp, i32, C.c_float, vp, C.c_longlong, vp, vp]
     L.pt_chunk_default_config.restype = None
     L.pt_chunk_default_config.argtypes = [C.POINTER(ChunkConfig), i32, i32]
     L.pt_chunk_create.argtypes = [C.POINTER(ChunkConfig), C.POINTER(vp)]
