@@ -71,6 +71,7 @@ void step_impl(Real *positions, int *edges, Real *costs, Real *temperatures, int
     if (pt_graph_upload(s.engine, s.pos.data(), ed.data(), edgeCount, s.ecount.data(), nullptr, nullptr, s.temps.data()) != PT_OK) return;
     if (pt_graph_set_step(s.engine, s.calls) != PT_OK) return;
     if (pt_graph_run(s.engine, 1) != PT_OK) return;
+    // a device-side failure (a cost term out of range, ...) comes back from the download: outputs stay untouched
     if (pt_graph_download(s.engine, s.pos.data(), nullptr, 0, nullptr, s.costs.data()) != PT_OK) return;
     s.calls++;
     for (size_t i = 0; i < np; i++) positions[i] = (Real)s.pos[i];

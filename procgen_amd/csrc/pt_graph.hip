@@ -111,6 +111,23 @@ int drain_events(pt_graph_engine *e)
 
 int launch_init(pt_graph_engine *e, const GraphParams &P, int write_cost);
 
+// What a kernel can only flag reaches the caller when the stream is next waited for: a cost term
+// outside the exact sums' range (the tracked cost is then wrong), injected draws that ran out, a
+// cluster of workgroups that lost a member.  The bits stay set until the next upload.  (A full edge
+// list, PT_ERR_CAPACITY, is a defined no-op move and only shows in the statistics.)
+int device_status(const void *d_status)
+{
+    unsigned bits = 0;
+    PT_HIP_TRY(hipMemcpy(&bits, d_status, sizeof bits, hipMemcpyDeviceToHost));
+    if (bits & (1u << PT_ERR_CLUSTER_TIMEOUT))
+        return pt::set_error(PT_ERR_CLUSTER_TIMEOUT, "workgroups sharing one replica lost each other (the device was not theirs alone); the run stopped early");
+    if (bits & (1u << PT_ERR_NUMERIC_RANGE))
+        return pt::set_error(PT_ERR_NUMERIC_RANGE, "a cost term was not finite or reached 2^62: the tracked costs are not valid");
+    if (bits & (1u << PT_ERR_STREAM_EXHAUSTED))
+        return pt::set_error(PT_ERR_STREAM_EXHAUSTED, "the injected draws are shorter than the run");
+    return PT_OK;
+}
+
 int launch_steps(pt_graph_engine *e, long long step0, int nsteps)
 {
     if (nsteps <= 0) return PT_OK;
@@ -257,7 +274,7 @@ int check_convergence(pt_graph_engine *e, double strictness, int iteration, pt_c
     if (rc) return rc;
     PT_HIP_TRY(hipMemcpyAsync(out, e->conv_out.p, sizeof(pt_convergence_metrics) * (size_t)e->G, hipMemcpyDeviceToHost, e->stream));
     PT_HIP_TRY(hipStreamSynchronize(e->stream));
-    return PT_OK;
+    return device_status(e->status.p);
 }
 
 }  // namespace
@@ -734,7 +751,7 @@ int pt_graph_upload(pt_graph_engine *e, const float *positions, const int32_t *e
     { int rc = launch_init(e, e->P, 1); if (rc) return rc; }
     PT_HIP_TRY(hipStreamSynchronize(st));
     e->uploaded = true;
-    return PT_OK;
+    return device_status(e->status.p);      // an initial cost outside the exact sums' range
 }
 
 int pt_graph_set_draws(pt_graph_engine *e, const double *chain_u, int64_t steps, const double *swap_u, int64_t passes)
@@ -912,7 +929,7 @@ int pt_graph_read_energies(pt_graph_engine *e, double *dst)
     DeviceGuard guard(e->device);
     PT_HIP_TRY(hipMemcpyAsync(dst, e->cost.p, sizeof(double) * (size_t)e->R, hipMemcpyDefault, e->stream));
     PT_HIP_TRY(hipStreamSynchronize(e->stream));
-    return PT_OK;
+    return device_status(e->status.p);
 }
 
 int pt_graph_swap_pass(pt_graph_engine *e, const double *d_energy_all_replicas)
@@ -932,7 +949,7 @@ int pt_graph_sync(pt_graph_engine *e)
     if (!e) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null engine");
     DeviceGuard guard(e->device);
     PT_HIP_TRY(hipStreamSynchronize(e->stream));
-    return PT_OK;
+    return device_status(e->status.p);
 }
 
 int pt_graph_replica_slots(pt_graph_engine *e, int32_t *slot_of_replica_all)
@@ -1000,7 +1017,7 @@ int pt_graph_download(pt_graph_engine *e, float *positions, int32_t *edges, int3
         PT_HIP_TRY(hipMemcpy(hc.data(), e->cost.p, sizeof(double) * R, hipMemcpyDeviceToHost));
         for (int g = 0; g < G; g++) for (int t = 0; t < T; t++) costs[output_row(e, sor, g, t)] = hc[g * T + t];
     }
-    return PT_OK;
+    return device_status(e->status.p);      // the arrays are filled either way; the code says whether to trust them
 }
 
 int pt_graph_cost_terms(pt_graph_engine *e, double *terms)
