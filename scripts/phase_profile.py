@@ -32,6 +32,8 @@ def main():
     ponly = int(os.environ.get("PERTURB_ONLY", "0"))
     wl = wlm.graph_workload("c2", n, R, 1)
     flags = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    if os.environ.get("ALL_TEMPS"):                 # every replica at one temperature (5.0: four topology moves in five)
+        wl["temperatures"][:] = float(os.environ["ALL_TEMPS"])
     eng = GraphEngine(n, wl["ecap"], R, 1, seed="procgen-bench/c2", block_threads=block, cluster_size=cluster, flags=flags,
                       mutation_mode=nt.MUT_PERTURB_ONLY if ponly else nt.MUT_ADAPTIVE)
     inc = eng.info()["incremental"]
