@@ -5,21 +5,25 @@ Metric (BASELINE.json): Metropolis proposals/sec (whole node), 10k-node graph x 
 
   python bench.py --gpus N --steps K --warmup W
 
-One "step" is one swap interval of the workload: f = swapFrequency(10000) = 200
-iterations of ParallelTempering.run's loop on every replica (propose + full
-weighted cost + Metropolis accept) followed by the sequential swap pass.  The
-engine's default evaluation is incremental: the exact fixed-point cost sums are
-updated by the terms the move changes, which yields bit for bit the cost a full
-re-evaluation yields (--full-evaluation times the full re-evaluation kernels).  With N > 1 every rank (one process per GPU, launched by
-torch.distributed.run) runs its own 64-replica ladder -- independent chains
-shard across GPUs, so there is no data-path collective -- and the whole-job
-value is the sum over ranks divided by the slowest rank's time ("weak").
-All inputs are resident in HBM before the timed region.
+One "step" is one swap interval of the workload: f = swapFrequency(10000) = 200 iterations of
+ParallelTempering.run's loop on every replica (propose + weighted cost + Metropolis accept) followed by
+the sequential swap pass.  The engine's default evaluation is incremental: the exact fixed-point cost
+sums are updated by the terms the move changes, which yields bit for bit the cost a full re-evaluation
+yields (--full-evaluation times the full re-evaluation kernels).  Without --steps the timed region is
+sized to last about 0.6 s.
 
-Rank 0 prints ONE JSON line.
+Multi-GPU (one process per GPU, launched by torch.distributed.run):
+  default          every rank runs its own ladder: independent chains shard across GPUs with no
+                   data-path collective; the whole-job value is the sum over ranks divided by the slowest
+                   rank's time ("weak").
+  --split-ladder   ONE ladder of 16 x N temperatures over N ranks (BASELINE configs[4] at N = 8: 10^6 nodes,
+                   128 replicas): every swap interval ends with an all-gather of the per-replica energies
+                   (RCCL over xGMI) and the identical swap pass on every rank; states never move.
+All inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -29,25 +33,33 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X FP32 vector spec peak
+TIMED_SECONDS = 0.6            # length of the timed region when --steps is not given
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=0, help="timed swap intervals (0: as many as fill about 0.6 s)")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--nodes", type=int, default=10000)
-    ap.add_argument("--replicas", type=int, default=64, help="temperatures per ladder")
+    ap.add_argument("--nodes", type=int, default=0, help="nodes per graph (default 10000; 1000000 with --split-ladder)")
+    ap.add_argument("--replicas", type=int, default=0, help="temperatures per ladder held by one GPU (default 64; 16 with --split-ladder)")
     ap.add_argument("--ladders", type=int, default=1, help="independent ladders per GPU (configs[3]: --nodes 1000 --replicas 16 --ladders 512)")
     ap.add_argument("--layout", default="box", choices=["box", "sphere"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full-evaluation", action="store_true", help="re-evaluate the full cost per proposal")
-    ap.add_argument("--cluster", type=int, default=0, help="workgroups per replica of the full evaluation (0 = choose)")
+    ap.add_argument("--cluster", type=int, default=0, help="workgroups per replica (0 = choose)")
+    ap.add_argument("--split-ladder", action="store_true",
+                    help="one ladder of replicas x N temperatures split over the N ranks, energies all-gathered per swap interval")
     ap.add_argument("--workload", default="graphs", choices=["graphs", "chunks"],
                     help="graphs: BASELINE configs[1] (the headline); chunks: configs[2], 32^3 voxel chunks")
     ap.add_argument("--chunks", type=int, default=4096, help="chunks per GPU of the chunk workload")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if not a.nodes:
+        a.nodes = 1000000 if a.split_ladder else 10000
+    if not a.replicas:
+        a.replicas = 16 if a.split_ladder else 64
+    return a
 
 
 # PROCGEN_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend, to rehearse the N > 1 code path
@@ -69,50 +81,71 @@ def init_ranks(torch, dist, world, local_rank):
     return torch.cuda.current_device()
 
 
+def host_cores(limit):
+    return max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 16, limit))
+
+
 def cpu_baseline(wl, f):
-    """Time the CPU oracle (a port of the reference's F# path; oracle/) on a bounded sample of
-    the same workload: the reference's own algorithms and summation order, one thread per
-    chain capped at the host's cores (reference src/Execution.fs:31-39)."""
+    """Time the CPU oracle (a port of the reference's F# path; oracle/) on a bounded sample of the same
+    workload: the reference's own algorithms and summation order, one thread per chain capped at the
+    host's cores (reference src/Execution.fs:31-39).  The reference's list-scan search is O(V E) per
+    proposal, so beyond 50 000 nodes only the variant with CSR search and grid hash is timed."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
     import parity_util as pu
 
-    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 16, wl["temps"])
+    T, n = wl["temps"], wl["n"]
+    one = dict(wl)                                  # one ladder is sample enough
+    for k in ("pos", "edges", "ecount", "temperatures", "kind", "value"):
+        one[k] = wl[k][:1]
+    one["groups"] = 1
+    one["temperatures"] = one["temperatures"][:, :T]
+    cores = host_cores(T)
 
     def timed(algo, sum_mode, iters):
         t0 = time.perf_counter()
-        pu.oracle_run(wl, iters, f, seed="bench-cpu", algo=algo, sum_mode=sum_mode, trace=False, threads=cores)
+        pu.oracle_run(one, iters, f, seed="bench-cpu", algo=algo, sum_mode=sum_mode, trace=False, threads=cores)
         return time.perf_counter() - t0
 
+    modes = [("optimised", ob.ALGO_OPTIMISED, ob.SUM_FSHARP)]
+    if n <= 50000:
+        modes.insert(0, ("faithful", ob.ALGO_FAITHFUL, ob.SUM_FSHARP))
     out = {}
-    for name, algo, sum_mode in (("faithful", ob.ALGO_FAITHFUL, ob.SUM_FSHARP), ("optimised", ob.ALGO_OPTIMISED, ob.SUM_FSHARP)):
+    for name, algo, sum_mode in modes:
         t_init = timed(algo, sum_mode, 0)               # initial costs only
         iters, t = 1, timed(algo, sum_mode, 1)
-        budget = ARGS.cpu_seconds / 2.0
-        while t - t_init < budget / 4 and iters < 4096:  # grow the sample until it is long enough to time
+        budget = ARGS.cpu_seconds / len(modes)
+        while t - t_init < budget / 4 and iters < 4096 and t < budget:      # grow the sample until it is long enough to time
             iters *= 4
             t = timed(algo, sum_mode, iters)
-        out[name] = dict(rate=wl["temps"] * iters / max(t - t_init, 1e-9), iters=iters, seconds=t - t_init)
-    return dict(value=out["faithful"]["rate"], unit="proposals/s", cores=cores, kind="port",
-                sample=f"{wl['temps']} replicas x {out['faithful']['iters']} iterations of the 10k-node workload, "
-                       f"reference algorithms (list-scan BFS, dictionary spatial hash), {out['faithful']['seconds']:.1f} s",
-                optimised_value=out["optimised"]["rate"],
-                optimised_sample=f"{wl['temps']} replicas x {out['optimised']['iters']} iterations, CSR BFS + grid hash, "
-                                 f"{out['optimised']['seconds']:.1f} s")
+        out[name] = dict(rate=T * iters / max(t - t_init, 1e-9), iters=iters, seconds=t - t_init)
+    opt = out["optimised"]
+    rec = dict(unit="proposals/s", cores=cores, kind="port", optimised_value=opt["rate"],
+               optimised_sample=f"{T} replicas x {opt['iters']} iterations of the {n}-node workload, CSR search + grid hash, "
+                                f"{opt['seconds']:.1f} s")
+    if "faithful" in out:
+        fa = out["faithful"]
+        rec.update(value=fa["rate"],
+                   sample=f"{T} replicas x {fa['iters']} iterations of the {n}-node workload, reference algorithms "
+                          f"(list-scan BFS, dictionary spatial hash), {fa['seconds']:.1f} s")
+    else:
+        rec.update(value=opt["rate"],
+                   sample=rec["optimised_sample"] + " (the reference's own list-scan search is O(V E) per proposal: "
+                          "not timed at this size; this figure flatters the CPU)")
+    return rec
 
 
-def measured_traffic(kernel, record="pmc_traffic.json"):
-    """HBM bytes per launch of the step kernel from the committed PMC passes (rocprofv3 cannot
-    run inside this process); None when no measurement of this kernel is on file."""
-    path = os.path.join(ROOT, "profiles", record)
+def pmc_record(name, kernel):
+    """A committed PMC measurement (rocprofv3 cannot run inside this process): HBM bytes per proposal of
+    `kernel`, or None when none is on file."""
     try:
-        with open(path) as fh:
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
             rec = json.load(fh)
-        if rec.get("kernel") == kernel:
-            return rec["hbm_bytes_per_launch"], rec.get("note", "")
+        if rec.get("kernel") == kernel and rec.get("proposals_per_launch"):
+            return rec["hbm_bytes_per_launch"] / rec["proposals_per_launch"], rec.get("note", "")
     except (OSError, ValueError, KeyError):
         pass
-    return None, "no PMC measurement of this kernel on file"
+    return None, "no PMC measurement of this kernel and shape on file"
 
 
 def chunk_cpu_baseline(wl, f):
@@ -123,7 +156,7 @@ def chunk_cpu_baseline(wl, f):
 
     cfg = tb.default_config(ob.SUM_FSHARP)
     T = wl["temps"]
-    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 16, T)
+    cores = host_cores(T)
 
     def timed(iters):
         t0 = time.perf_counter()
@@ -139,6 +172,49 @@ def chunk_cpu_baseline(wl, f):
     return dict(value=T * iters / max(t - t_init, 1e-9), unit="proposals/s", cores=cores, kind="port",
                 sample=f"one chunk ladder ({T} temperatures) x {iters} iterations, full terrain cost per proposal, "
                        f"{t - t_init:.1f} s")
+
+
+class Timed:
+    """Warm-up, then K steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+
+    def __init__(self, torch, dist, world, step_fn, sync_fn):
+        self.torch, self.dist, self.world, self.step_fn, self.sync_fn = torch, dist, world, step_fn, sync_fn
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+        self.sync_fn()
+
+    def max_over_ranks(self, x):
+        if self.world > 1:
+            tt = self.torch.tensor([x], dtype=self.torch.float64, device="cpu" if REHEARSAL else "cuda")
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            return float(tt.item())
+        return x
+
+    def run(self, before_timed):
+        for _ in range(ARGS.warmup):
+            self.step_fn()
+        self.sync_fn()
+        steps = ARGS.steps
+        if steps <= 0:                              # size the timed region: one more step, timed
+            self.barrier()
+            t0 = time.perf_counter()
+            self.step_fn()
+            self.sync_fn()
+            one = self.max_over_ranks(time.perf_counter() - t0)
+            steps = int(min(5000, max(2, math.ceil(TIMED_SECONDS / max(one, 1e-6)))))
+        before_timed()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step_fn()
+        self.sync_fn()
+        self.torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        self.barrier()
+        return steps, self.max_over_ranks(t1 - t0)
 
 
 def main_chunks():
@@ -163,50 +239,48 @@ def main_chunks():
     f = eng.swap_frequency
     eng.upload(tile(wl["density"]), tile(wl["moisture"]), tile(wl["temperature"]), tile(wl["material"]), tile(wl["temperatures"]))
     eng.run(1)
-    for _ in range(ARGS.warmup):
-        eng.run(f)
-    eng.sync()
-    eng.kernel_time(reset=True)
-    st0 = eng.stats()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(ARGS.steps):
-        eng.run(f)
-    eng.sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if REHEARSAL else "cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    st0 = {}
+
+    def before_timed():
+        eng.kernel_time(reset=True)
+        st0.update(eng.stats())
+
+    steps, elapsed = Timed(torch, dist, world, lambda: eng.run(f), eng.sync).run(before_timed)
     kms, klaunch = eng.kernel_time()
     st1 = eng.stats()
     props = st1["proposals"] - st0["proposals"]
-    assert props == ARGS.steps * f * G * T and st1["status_bits"] == 0
+    assert props == steps * f * G * T and st1["status_bits"] == 0
     if rank == 0:
         V = wl["V"]
-        bpp = wlm.chunk_algorithmic_bytes_per_proposal(V)
         per_launch = props / max(klaunch, 1)
         launch_s = kms / max(klaunch, 1) * 1e-3
+        traffic, traffic_note = pmc_record("pmc_traffic_chunks.json", "pt_chunk_steps_kernel")
+        ref_bpp = wlm.chunk_algorithmic_bytes_per_proposal(V)
+        # bytes one incremental proposal must move: the voxel's record and its six neighbours' (16 B each),
+        # the replica's header, one record written back
+        alg_bpp = 7 * 16 + 64 + 16
+        bpp = traffic if traffic is not None else alg_bpp
         achieved = bpp * per_launch / launch_s / 1e9
-        traffic, traffic_note = measured_traffic("pt_chunk_steps_kernel" if G == 4096 else None, "pmc_traffic_chunks.json")
         line = {
             "metric": "Metropolis proposals/sec (whole node), 32^3 voxel chunks x 6 temperatures", "value": props * world / elapsed,
-            "unit": "proposals/s", "n_gpus": world, "steps": ARGS.steps, "warmup": ARGS.warmup,
-            "ms_per_step": elapsed / ARGS.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "unit": "proposals/s", "n_gpus": world, "steps": steps, "warmup": ARGS.warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 voxel fields, f64 cost, i128 fixed-point sums", "data": "synthetic",
             "config": {"workload": f"configs[2]: {G} voxel chunks (32^3) x {T} temperatures per GPU, terrain constraints, "
                                    f"ladder 0.1-5.0, swap every {f}, incremental exact cost update per proposal",
                        "chunks_per_gpu": G, "temperatures": T, "swap_frequency": f,
                        "accept_rate": (st1["accepted"] - st0["accepted"]) / max(props, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_note": traffic_note, "kernel": "pt_chunk_steps_kernel",
-                         "kernel_ms_avg": kms / max(klaunch, 1),
-                         "launches": klaunch, "proposals_per_launch": per_launch, "algorithmic_bytes_per_proposal": bpp,
-                         "algorithmic_note": "bytes one FULL terrain-cost evaluation touches (the reference's work per proposal)"},
+                         "traffic": None if traffic is None else traffic * per_launch,
+                         "traffic_note": traffic_note, "kernel": "pt_chunk_steps_kernel",
+                         "bytes_per_proposal": bpp,
+                         "bytes_note": "HBM bytes per proposal: the committed PMC measurement of this kernel when one is on file, "
+                                       "else what one incremental proposal must move (7 voxel records, header, one write)",
+                         "kernel_ms_avg": kms / max(klaunch, 1), "launches": klaunch, "proposals_per_launch": per_launch,
+                         "reference_work": {"bytes_per_proposal": ref_bpp, "rate_GBs": ref_bpp * per_launch / launch_s / 1e9,
+                                            "note": "bytes one FULL terrain-cost evaluation touches (the reference's work per "
+                                                    "proposal) times the proposal rate: a throughput in units of reference work, "
+                                                    "not bytes moved"}},
         }
         if not ARGS.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = chunk_cpu_baseline(wl, f)
@@ -229,66 +303,67 @@ def main():
     import numpy as np
     from procgen_amd import native as nt
     from procgen_amd import workloads as wlm
+    from procgen_amd.distributed import GraphEngineShard, SplitLadder
     from procgen_amd.engine import GraphEngine
 
     n, R = ARGS.nodes, ARGS.replicas
     G = ARGS.ladders
-    distinct = min(G, 16)                        # distinct ladders generated; tiled when more are asked for
-    wl = wlm.graph_workload("c2", n, R, distinct, layout=ARGS.layout, index=rank)
-    if G > distinct:
-        reps = (G + distinct - 1) // distinct
-        for k in ("pos", "edges", "ecount", "temperatures", "kind", "value"):
-            wl[k] = np.ascontiguousarray(np.tile(wl[k], (reps,) + (1,) * (wl[k].ndim - 1))[:G])
-        wl["groups"] = G
-    eng = GraphEngine(n, wl["ecap"], R, G, seed="procgen-bench/c2", device=dev, group_base=rank * G,
-                      flags=nt.FLAG_FULL_EVALUATION if ARGS.full_evaluation else 0, cluster_size=ARGS.cluster)
+    split = ARGS.split_ladder
+    flags = nt.FLAG_FULL_EVALUATION if ARGS.full_evaluation else 0
+    if split:
+        # one ladder of R x world temperatures; this rank holds replicas [rank R, (rank + 1) R)
+        assert G == 1, "--split-ladder runs one ladder"
+        Tl = R * world
+        whole = wlm.graph_workload("c5", n, Tl, 1, layout=ARGS.layout)
+        wl = dict(whole)
+        for k in ("pos", "edges", "ecount"):
+            wl[k] = np.ascontiguousarray(whole[k][:, rank * R:(rank + 1) * R])
+        wl["temps"] = R
+        eng = GraphEngine(n, wl["ecap"], R, 1, seed="procgen-bench/c5", device=dev, ladder_temp_count=Tl,
+                          ladder_slot_base=rank * R, flags=flags, cluster_size=ARGS.cluster)
+        driver = SplitLadder(GraphEngineShard(eng), device=torch.device("cpu") if REHEARSAL else None)
+    else:
+        distinct = min(G, 16)                        # distinct ladders generated; tiled when more are asked for
+        wl = wlm.graph_workload("c2", n, R, distinct, layout=ARGS.layout, index=rank)
+        if G > distinct:
+            reps = (G + distinct - 1) // distinct
+            for k in ("pos", "edges", "ecount", "temperatures", "kind", "value"):
+                wl[k] = np.ascontiguousarray(np.tile(wl[k], (reps,) + (1,) * (wl[k].ndim - 1))[:G])
+            wl["groups"] = G
+        eng = GraphEngine(n, wl["ecap"], R, G, seed="procgen-bench/c2", device=dev, group_base=rank * G,
+                          flags=flags, cluster_size=ARGS.cluster)
+        driver = None
     info = eng.info()
     f = eng.swap_frequency
     eng.upload(wl["pos"], wl["edges"], wl["ecount"], wl["temperatures"], wl["kind"], wl["value"])
-    eng.run(1)                                  # step 0 and its swap pass: intervals then start at 1, f+1, ...
-    for _ in range(ARGS.warmup):
-        eng.run(f)
-    eng.sync()
-    eng.kernel_time(reset=True)
-    st0 = eng.stats()
+    step_fn = (lambda: driver.run(f)) if split else (lambda: eng.run(f))
+    (driver.run if split else eng.run)(1)        # step 0 and its swap pass: intervals then start at 1, f+1, ...
+    st0, g0 = {}, [0]
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        eng.sync()
+    def before_timed():
+        eng.kernel_time(reset=True)
+        st0.update(eng.stats())
+        g0[0] = driver.gathers if split else 0
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(ARGS.steps):
-        eng.run(f)
-    eng.sync()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    barrier()
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if REHEARSAL else "cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    steps, elapsed = Timed(torch, dist, world, step_fn, eng.sync).run(before_timed)
 
     kms, klaunch = eng.kernel_time()
     st1 = eng.stats()
     res = eng.download(positions=False, edges=True)
     proposals_rank = st1["proposals"] - st0["proposals"]
-    assert proposals_rank == ARGS.steps * f * R * G, (proposals_rank, ARGS.steps * f * R * G)
+    assert proposals_rank == steps * f * R * G, (proposals_rank, steps * f * R * G)
     assert st1["status_bits"] == 0, f"device status bits {st1['status_bits']:#x}"
+    gathers = (driver.gathers - g0[0]) if split else 0
+    assert not split or gathers == steps, (gathers, steps)
     total = proposals_rank * world
     value = total / elapsed
 
     if rank == 0:
         e_mean = float(res["ecount"].mean())
-        bytes_per_prop = wlm.algorithmic_bytes_per_proposal(n, e_mean)
-        flops_per_prop = wlm.algorithmic_flops_per_proposal(n, e_mean)
+        ref_bytes = wlm.algorithmic_bytes_per_proposal(n, e_mean)
+        ref_flops = wlm.algorithmic_flops_per_proposal(n, e_mean)
         props_per_launch = proposals_rank / max(klaunch, 1)
         launch_s = (kms / max(klaunch, 1)) * 1e-3
-        achieved = bytes_per_prop * props_per_launch / launch_s / 1e9
-        valu = flops_per_prop * props_per_launch / launch_s / 1e12
         if info["incremental"]:
             kernel = ("pt_graph_delta_kernel" if info["lds_placement"]
                       else "pt_graph_bigc_kernel" if info["cluster_size"] > 1 else "pt_graph_big_kernel")
@@ -299,52 +374,73 @@ def main():
             kernel, how = "pt_graph_cluster_kernel", f"full cost re-evaluation per proposal by {info['cluster_size']} workgroups per replica"
         else:
             kernel, how = "pt_graph_steps_kernel", "full cost re-evaluation per proposal"
-        # the PMC record on file was taken at the headline shape only
-        if (n, R, G) == (10000, 64, 1):
-            traffic, traffic_note = measured_traffic(kernel)
-        elif (n, R, G) == (1000000, 16, 1):
-            traffic, traffic_note = measured_traffic(kernel, "pmc_traffic_1m.json")
+        headline = (n, R, G) == (10000, 64, 1) and not split
+        traffic_pp, traffic_note = (pmc_record("pmc_traffic.json", kernel) if headline else
+                                    pmc_record("pmc_traffic_1m.json", kernel) if (n, R, G) == (1000000, 16, 1) else
+                                    (None, "no PMC measurement of this kernel and shape on file"))
+        valu = ref_flops * props_per_launch / launch_s / 1e12
+        hbm_equiv = ref_bytes * props_per_launch / launch_s / 1e9
+        common = {"kernel": kernel, "kernel_ms_avg": kms / max(klaunch, 1), "launches": klaunch,
+                  "proposals_per_launch": props_per_launch, "lds_bytes_per_workgroup": info["lds_bytes"],
+                  "block_threads": info["block_threads"],
+                  "traffic": None if traffic_pp is None else traffic_pp * props_per_launch, "traffic_note": traffic_note}
+        if info["lds_placement"]:
+            # replica state resident in LDS: HBM sees next to nothing, the bound is vector issue
+            measured_valu = None
+            if headline and kernel == "pt_graph_delta_kernel":
+                try:
+                    with open(os.path.join(ROOT, "profiles", "pmc_sq.json")) as fh:
+                        sq = json.load(fh)["counters"]
+                    lane_instr = sq["SQ_INSTS_VALU"] * 64.0 / launch_s         # VALU lane-instructions per second, this run's launch time
+                    measured_valu = {"valu_wave_instructions_per_launch": sq["SQ_INSTS_VALU"],
+                                     "salu_wave_instructions_per_launch": sq["SQ_INSTS_SALU"],
+                                     "lds_wave_instructions_per_launch": sq["SQ_INSTS_LDS"],
+                                     "lane_instructions_per_s": lane_instr,
+                                     # peak issue: one lane-instruction per lane per clock = half the FMA flop peak
+                                     "frac_of_peak_issue": lane_instr / (FP32_VALU_PEAK_TFLOPS * 1e12 / 2.0),
+                                     "note": "rocprofv3 --pmc SQ_INSTS_* of one launch (profiles/pmc_sq.json) over this run's "
+                                             "launch time; 64 of 256 CUs hold a replica"}
+                except (OSError, ValueError, KeyError):
+                    pass
+            roofline = dict(common, bound="valu", achieved=valu, peak=FP32_VALU_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=valu / FP32_VALU_PEAK_TFLOPS, lane_ops_per_proposal=ref_flops,
+                            algorithmic_note="lane-ops one FULL cost evaluation needs (the reference's work per proposal: "
+                                             "11E + 30N + (27 + 10 k)N + 2E) times the proposal rate, against the fp32 vector "
+                                             "peak; the incremental kernel does less work for the same result",
+                            measured=measured_valu,
+                            hbm_equivalent={"rate_GBs": hbm_equiv, "bytes_per_proposal": ref_bytes,
+                                            "note": "bytes one full evaluation touches times the proposal rate (reference work, "
+                                                    "not bytes moved: the state is in LDS)"})
         else:
-            traffic, traffic_note = measured_traffic(None)
-        measured_valu = None
-        if (n, R, G) == (10000, 64, 1) and kernel == "pt_graph_delta_kernel":
-            try:
-                with open(os.path.join(ROOT, "profiles", "pmc_sq.json")) as fh:
-                    sq = json.load(fh)["counters"]
-                lane_instr = sq["SQ_INSTS_VALU"] * 64.0 / launch_s         # VALU lane-instructions per second, this run's launch time
-                # peak issue: one lane-instruction per lane per clock = half the FMA flop peak
-                measured_valu = {"valu_wave_instructions_per_launch": sq["SQ_INSTS_VALU"],
-                                 "salu_wave_instructions_per_launch": sq["SQ_INSTS_SALU"],
-                                 "lds_wave_instructions_per_launch": sq["SQ_INSTS_LDS"],
-                                 "lane_instructions_per_s": lane_instr,
-                                 "frac_of_peak_issue": lane_instr / (FP32_VALU_PEAK_TFLOPS * 1e12 / 2.0),
-                                 "note": "rocprofv3 --pmc SQ_INSTS_* of one launch (profiles/pmc_sq.json) over this run's launch "
-                                         "time; 64 of 256 CUs hold a replica"}
-            except (OSError, ValueError, KeyError):
-                pass
+            # replica state streamed from HBM
+            moved = (n * 20 + 8 * e_mean)               # one perturbation: positions twice + distances, edge endpoints
+            bpp = traffic_pp if traffic_pp is not None else moved
+            achieved = bpp * props_per_launch / launch_s / 1e9
+            roofline = dict(common, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                            bytes_per_proposal=bpp,
+                            bytes_note="HBM bytes per proposal: the committed PMC measurement of this kernel and shape when one is "
+                                       "on file, else what one incremental perturbation streams (8E + 12N + 8N)",
+                            reference_work={"bytes_per_proposal": ref_bytes, "rate_GBs": hbm_equiv,
+                                            "lane_ops_rate_TFLOPs": valu})
+        shape = ("configs[1]" if headline else "configs[4] shape" if split else "other shape")
         line = {
-            "metric": "Metropolis proposals/sec (whole node), 10k-node graph x 64 replicas" if (n, R, G) == (10000, 64, 1)
-                      else f"Metropolis proposals/sec (whole node), {n}-node graph x {R * G} replicas",
-            "value": value, "unit": "proposals/s", "n_gpus": world, "steps": ARGS.steps, "warmup": ARGS.warmup,
-            "ms_per_step": elapsed / ARGS.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": "Metropolis proposals/sec (whole node), 10k-node graph x 64 replicas" if headline
+                      else f"Metropolis proposals/sec (whole node), {n}-node graph x {R * G * (world if split else 1)} replicas"
+                           f"{' (one ladder split over the GPUs)' if split else ''}",
+            "value": value, "unit": "proposals/s", "n_gpus": world, "steps": steps, "warmup": ARGS.warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 positions, f64 cost, i128 fixed-point sums", "data": "synthetic",
-            "config": {"workload": f"{'configs[1]' if (n, R, G) == (10000, 64, 1) else 'other shape'}: {n}-node spatial graph x {R} replicas"
+            "config": {"workload": f"{shape}: {n}-node spatial graph x {R} replicas"
                                    f"{'' if G == 1 else f' x {G} ladders'} per GPU, E~1.5N, "
-                                   f"uniform-box layout, ladder 0.5-5.0, swap every {f}, {how}",
+                                   f"uniform-box layout, ladder 0.5-5.0"
+                                   f"{f' of {R * world} temperatures split over {world} ranks, energies all-gathered per swap interval' if split else ''}"
+                                   f", swap every {f}, {how}",
                        "nodes": n, "replicas_per_gpu": R * G, "ladders_per_gpu": G, "edges_mean": e_mean, "swap_frequency": f,
                        "iterations_per_step": f, "accept_rate": (st1["accepted"] - st0["accepted"]) / max(proposals_rank, 1),
-                       "swap_rate": st1["swaps"] / max(st1["swap_attempts"], 1)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": kernel, "kernel_ms_avg": kms / max(klaunch, 1), "launches": klaunch,
-                         "proposals_per_launch": props_per_launch,
-                         "algorithmic_bytes_per_proposal": bytes_per_prop,
-                         "algorithmic_note": "bytes and lane-ops one FULL cost evaluation touches (the reference's work per "
-                                             "proposal); the engine may do less work for the same result",
-                         "lds_bytes_per_workgroup": info["lds_bytes"], "block_threads": info["block_threads"],
-                         "valu": {"achieved": valu, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": valu / FP32_VALU_PEAK_TFLOPS, "lane_ops_per_proposal": flops_per_prop,
-                                  "measured": measured_valu}},
+                       "swap_rate": st1["swaps"] / max(st1["swap_attempts"], 1),
+                       "energy_gathers": gathers if split else None,
+                       "backend": ("gloo (rehearsal)" if REHEARSAL else "nccl") if world > 1 else None},
+            "roofline": roofline,
         }
         if not ARGS.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(wl, f)

@@ -27,18 +27,25 @@ class GraphEngineShard:
         self.local_count = engine.T
         self.ladder_count = engine.Tl
         self.device = torch.device("cuda", torch.cuda.current_device())
+        self.stream = torch.cuda.ExternalStream(engine.stream())        # the engine's own HIP stream, as torch sees it
+        self.staged = torch.zeros(self.ladder_count, dtype=torch.float64, device=self.device)
 
     def run_to_swap_point(self, max_steps):
         return self.engine.run_to_swap_point(max_steps)
 
     def local_energies(self, out):
+        """out: a host or a device tensor; the copy waits for the steps launched so far."""
         assert out.dtype == torch.float64 and out.numel() == self.local_count and out.is_contiguous()
         self.engine.read_energies(out.data_ptr())
 
     def swap_pass(self, all_energies):
-        assert all_energies.dtype == torch.float64 and all_energies.numel() == self.ladder_count
-        assert all_energies.is_cuda and all_energies.is_contiguous()
-        torch.cuda.current_stream().synchronize()      # the gather ran on torch's stream, the pass runs on the engine's
+        assert all_energies.dtype == torch.float64 and all_energies.numel() == self.ladder_count and all_energies.is_contiguous()
+        if not all_energies.is_cuda:                    # gathered on the host (gloo): stage on the device
+            self.staged.copy_(all_energies, non_blocking=False)
+            all_energies = self.staged
+        # the gather (or the staging copy) ran on torch's stream, the pass runs on the engine's: the engine's
+        # stream waits for torch's, the host does not
+        self.stream.wait_stream(torch.cuda.current_stream())
         self.engine.swap_pass(all_energies.data_ptr())
 
 

@@ -178,6 +178,10 @@ class GraphEngine:
         nt.check(self.L.pt_graph_kernel_time(self.h, C.byref(ms), C.byref(n), int(reset)))
         return ms.value, n.value
 
+    def stream(self):
+        """The engine's HIP stream as an integer handle (e.g. for torch.cuda.ExternalStream)."""
+        return int(self.L.pt_graph_stream(self.h) or 0)
+
 
 class ChunkEngine:
     """Batched parallel tempering over 32^3 voxel chunks (pt_chunk_* of the C ABI): `group_count` chunks,

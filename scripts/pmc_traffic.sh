@@ -28,7 +28,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             kernel = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").strip()
     last = sorted(agg, key=int)[-1]
     out[c] = agg[last]
-rec = {"kernel": kernel, "fetch_size_kb": out["FETCH_SIZE"], "write_size_kb": out["WRITE_SIZE"],
+ppl = None
+for line in open(f"{R}/gpurun_out/{OUT}_WRITE_SIZE.log"):
+    if line.startswith("{") and "proposals_per_launch" in line:
+        ppl = json.loads(line)["roofline"]["proposals_per_launch"]
+rec = {"kernel": kernel, "fetch_size_kb": out["FETCH_SIZE"], "write_size_kb": out["WRITE_SIZE"], "proposals_per_launch": ppl,
        "hbm_bytes_per_launch": 2.0 * out["FETCH_SIZE"] * 1024.0 + out["WRITE_SIZE"] * 1024.0,
        "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes, last launch of bench.py --steps 2; "
                "bytes = 2 x FETCH_SIZE (gfx950 read-request correction) + WRITE_SIZE, KB = 1024 B"}

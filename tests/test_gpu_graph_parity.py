@@ -297,6 +297,39 @@ def test_streaming_cluster_matches_one_workgroup_at_150k_nodes(gpu_lib):
     assert (one["trace"]["kind"] == 2).any() and len(np.unique(one["trace"]["reach0"])) > 1
 
 
+def test_million_node_replicas_track_their_cost(gpu_lib):
+    """BASELINE configs[4]'s replica size: 10^6 nodes (two replicas here), 16 workgroups per replica.  After a
+    few dozen proposals the tracked cost of each replica equals a from-scratch evaluation on the device and
+    the oracle's evaluation of the downloaded state, bit for bit, and the run equals the one-workgroup
+    kernel's (whose trajectories the oracle pins at 70 000 nodes)."""
+    n, T, iters, f = 1000000, 2, 36, 16
+    wl = wlm.graph_workload("c5-test", n, T, 1)
+    wl["temperatures"][:] = [[5.0, 0.5]]
+    runs = []
+    for members in (0, 1):
+        with GraphEngine(n, wl["ecap"], T, 1, swap_frequency=f, seed="c5-test", cluster_size=members) as eng:
+            info = eng.info()
+            assert info["incremental"] and not info["lds_placement"]
+            assert (info["cluster_size"] == 16) if members == 0 else (info["cluster_size"] == 1)
+            eng.upload(wl["pos"], wl["edges"], wl["ecount"], wl["temperatures"], wl["kind"], wl["value"])
+            eng.run(iters)
+            res = eng.download()
+            res["terms"], res["stats"], res["slots"] = eng.cost_terms(), eng.stats(), eng.replica_slots()
+            runs.append(res)
+    many, one = runs
+    assert many["stats"]["status_bits"] == 0 and one["stats"]["status_bits"] == 0
+    assert many["stats"]["proposals"] == iters * T and 0 < many["stats"]["accepted"] < iters * T
+    for k in ("cost", "ecount", "pos", "edges", "slots"):
+        assert np.array_equal(many[k], one[k]), k
+    assert many["stats"]["accepted"] == one["stats"]["accepted"] and many["stats"]["swaps"] == one["stats"]["swaps"]
+    assert np.array_equal(many["terms"][0, :, 6], many["cost"][0])
+    cfg = ob.default_config(ob.SUM_CANONICAL, ob.ALGO_OPTIMISED)
+    for t in range(T):
+        ec = many["ecount"][0, t]
+        o = ob.cost(many["pos"][0, t], many["edges"][0, t, :ec], wl["kind"][0], wl["value"][0], cfg)
+        assert o.total == many["cost"][0, t] and float(o.reach0) == many["terms"][0, t, 7]
+
+
 def test_trace_parity_injected_draws(gpu_lib):
     n, T, G, iters, f = 120, 5, 2, 500, 6
     wl = wlm.graph_workload("inject", n, T, G)

@@ -77,3 +77,26 @@ def test_single_rank_driver_equals_run(gpu_lib):
     eng.close()
     assert drv.gathers == (iters + f - 1) // f
     assert np.array_equal(res["cost"], whole["cost"]) and np.array_equal(res["pos"], whole["pos"])
+
+
+def test_bench_split_ladder_rehearsal_two_ranks(gpu_lib):
+    """bench.py --split-ladder as the driver launches it (torch.distributed.run, one process per rank), rehearsed
+    with two ranks on this one GPU over gloo: one 8-temperature ladder, four per rank, an energy all-gather per
+    swap interval."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PROCGEN_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", os.path.join(root, "bench.py"), "--gpus", "2", "--split-ladder", "--nodes", "3000",
+           "--replicas", "4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["energy_gathers"] == rec["steps"] == 3
+    assert rec["config"]["backend"].startswith("gloo") and rec["value"] > 0
