@@ -191,6 +191,12 @@ int pt_graph_upload(pt_graph_engine *e, const float *positions, const int32_t *e
 int pt_graph_set_draws(pt_graph_engine *e, const double *chain_u, int64_t steps,
                        const double *swap_u, int64_t passes);
 
+/* Per-ladder Philox keys, keys [G]: ladder g then draws from keys[g] with the temperature slot as the
+ * stream id (and swap stream 0), so that a ladder's trajectory does not depend on its index in the
+ * batch (e.g. keys[g] = pt_hash_coordinates(pt_seed_key(seed), x, y, z)).  Without this call all ladders
+ * share the engine's key and differ by stream id.  Call before pt_graph_run. */
+int pt_graph_set_ladder_keys(pt_graph_engine *e, const uint64_t *keys);
+
 /* Optional per-step trace for parity tests: records [max_steps][G*T] of
  * pt_trace_rec in slot order, and swap decisions [max_passes][G][Tl-1] bytes. */
 typedef struct pt_trace_rec {
@@ -360,6 +366,13 @@ void pt_chunk_destroy(pt_chunk_engine *e);
  * mutated); temperatures [G][T] fp64, index 0 hottest.  Computes the initial costs. */
 int pt_chunk_upload(pt_chunk_engine *e, const float *density, const float *moisture, const float *temperature,
                     const uint8_t *material, const double *temperatures);
+/* Chunk positions, xyz [G][3]: chunk g then draws from the key pt_hash_coordinates(engine key, x, y, z)
+ * (the chunk seed of reference src/Terrain.Generation.fs:172-176) with its temperature slot as the stream
+ * id, so its trajectory depends on (seed, position) and not on where in the batch it sits.  Without this
+ * call all chunks share the engine's key and chunk g draws from stream (group_base + g) * T + slot.
+ * pt_chunk_set_ladder_keys gives the per-chunk keys directly.  Call before pt_chunk_run. */
+int pt_chunk_set_positions(pt_chunk_engine *e, const int32_t *xyz);
+int pt_chunk_set_ladder_keys(pt_chunk_engine *e, const uint64_t *keys);
 /* injected draws: chain_u [G][T][steps][8], swap_u [G][passes][T-1] */
 int pt_chunk_set_draws(pt_chunk_engine *e, const double *chain_u, int64_t steps, const double *swap_u, int64_t passes);
 int pt_chunk_enable_trace(pt_chunk_engine *e, int64_t max_steps, int64_t max_passes);
@@ -383,6 +396,9 @@ int pt_debug_canonical_sum(const double *terms, int64_t n, double *out, int32_t 
 int pt_geometric_ladder(double t_min, double t_max, int32_t n, double *out);
 int32_t pt_swap_frequency(int32_t node_count);
 uint64_t pt_seed_key(const char *seed);
+/* DeterministicGeneration.hashCoordinates (reference src/Deterministic.fs:94-102): the seed of the chunk at
+ * (x, y, z) as Terrain.Generation.generate derives it (reference src/Terrain.Generation.fs:172-176). */
+uint64_t pt_hash_coordinates(uint64_t base_seed, int32_t x, int32_t y, int32_t z);
 
 #ifdef __cplusplus
 }

@@ -106,6 +106,19 @@ int32_t pt_swap_frequency(int32_t node_count)
     return f > 5 ? f : 5;
 }
 
+// reference src/Deterministic.fs:94-102 (`uint64 x` of a negative int sign-extends)
+uint64_t pt_hash_coordinates(uint64_t base_seed, int32_t x, int32_t y, int32_t z)
+{
+    uint64_t h = base_seed;
+    h ^= (uint64_t)(int64_t)x * 0xff51afd7ed558ccdULL;
+    h ^= h >> 33;
+    h ^= (uint64_t)(int64_t)y * 0xc4ceb9fe1a85ec53ULL;
+    h ^= h >> 33;
+    h ^= (uint64_t)(int64_t)z * 0xff51afd7ed558ccdULL;
+    h ^= h >> 33;
+    return h;
+}
+
 // little-endian u64 of SHA-256(utf8(seed))[0..8]: the same eight bytes
 // HashRNG.bytesToFloat reads (reference src/Deterministic.fs:14-22)
 uint64_t pt_seed_key(const char *seed)

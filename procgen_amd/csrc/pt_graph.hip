@@ -50,7 +50,7 @@ struct pt_graph_engine {
     SwapParams SP;
     DevBuf px, py, pz, ea, eb, et, ebuf, ecount, kind, value, origin, terminal, rowend, adj, adj4, cost, temps,
         slot_of_rep, rep_of_slot, cells, sorted, queue, bitmap, collbuf, comm, chain_u, swap_u, trace, swap_trace,
-        stats, swap_stats, status, terms, dacc, dreach, dvis, dparent, dparscr, dlabel, dlabscr, epk,
+        stats, swap_stats, status, terms, group_keys, dacc, dreach, dvis, dparent, dparscr, dlabel, dlabscr, epk,
         dparent32, dparscr32, bvis, bjmp, bdist, bcomm,
         conv_hist, conv_swaps, conv_swap_total, conv_out;
     int conv_window = 0;            // 0: convergence monitoring off
@@ -769,6 +769,20 @@ int pt_graph_set_draws(pt_graph_engine *e, const double *chain_u, int64_t steps,
     if (ns) PT_HIP_TRY(hipMemcpy(e->swap_u.p, swap_u, sizeof(double) * ns, hipMemcpyHostToDevice));
     e->P.chain_u = e->chain_u.as<double>(); e->P.draw_steps = steps;
     e->SP.swap_u = e->swap_u.as<double>(); e->SP.draw_passes = passes;
+    return PT_OK;
+}
+
+int pt_graph_set_ladder_keys(pt_graph_engine *e, const uint64_t *keys)
+{
+    pt::clear_error();
+    if (!e || !keys) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null engine or keys");
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    PT_HIP_TRY(hipStreamSynchronize(e->stream));
+    PT_HIP_TRY(e->group_keys.alloc(sizeof(uint64_t) * (size_t)e->G));
+    PT_HIP_TRY(hipMemcpy(e->group_keys.p, keys, sizeof(uint64_t) * (size_t)e->G, hipMemcpyHostToDevice));
+    e->P.group_keys = e->group_keys.as<unsigned long long>();
+    e->SP.group_keys = e->P.group_keys;
     return PT_OK;
 }
 

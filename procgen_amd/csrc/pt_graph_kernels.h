@@ -41,6 +41,10 @@ struct GraphParams {
     float inv_cell_f, d2_hi, d2_lo;     // see cell_coord() and the collision test
     int cell_pow2, collcap, collstride;     // collstride: threads per workgroup (rows of the deferred-collision lists)
     uint32_t key0, key1;
+    // When not null: ladder g draws from key group_keys[g] with its temperature slot as the stream id, so
+    // that its trajectory does not depend on where in the batch it sits (otherwise: one key, stream id
+    // (group_base + g) * Tl + slot).
+    const unsigned long long *group_keys;
     // state, replica-major
     float *px, *py, *pz;        // [R][N]
     int *ea, *eb;               // [R][C][2][Ecap]  ARRAY order (reverse of the reference's list order), double buffered
@@ -97,6 +101,7 @@ struct GraphParams {
 struct SwapParams {
     int G, Tl, group_base, rng_mode;
     uint32_t key0, key1;
+    const unsigned long long *group_keys;   // see GraphParams
     const double *temps;        // [G][Tl]
     int *slot_of_rep;           // [G][Tl]
     int *rep_of_slot;           // [G][Tl]

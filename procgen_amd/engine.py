@@ -88,6 +88,11 @@ class GraphEngine:
         passes = su.size // (self.G * max(self.Tl - 1, 1)) if self.Tl > 1 else 0
         nt.check(self.L.pt_graph_set_draws(self.h, nt.ptr(cu), steps, nt.ptr(su), passes))
 
+    def set_ladder_keys(self, keys):
+        """Per-ladder Philox keys [G]: a ladder's draws then depend on its key, not on its index in the batch."""
+        k = np.ascontiguousarray(keys, np.uint64).reshape(self.G)
+        nt.check(self.L.pt_graph_set_ladder_keys(self.h, nt.ptr(k)))
+
     def enable_trace(self, max_steps, max_passes):
         self._trace_steps, self._trace_passes = max_steps, max_passes
         nt.check(self.L.pt_graph_enable_trace(self.h, max_steps, max_passes))
@@ -240,6 +245,15 @@ class ChunkEngine:
         su = np.ascontiguousarray(swap_u, np.float64)
         passes = su.size // (self.G * max(self.T - 1, 1)) if self.T > 1 else 0
         nt.check(self.L.pt_chunk_set_draws(self.h, nt.ptr(cu), steps, nt.ptr(su), passes))
+
+    def set_positions(self, xyz):
+        """Chunk positions [G,3]: chunk g draws from hashCoordinates(engine key, x, y, z), as Terrain.Generation.generate seeds it."""
+        p = np.ascontiguousarray(xyz, np.int32).reshape(self.G, 3)
+        nt.check(self.L.pt_chunk_set_positions(self.h, nt.ptr(p)))
+
+    def set_ladder_keys(self, keys):
+        k = np.ascontiguousarray(keys, np.uint64).reshape(self.G)
+        nt.check(self.L.pt_chunk_set_ladder_keys(self.h, nt.ptr(k)))
 
     def enable_trace(self, max_steps, max_passes):
         nt.check(self.L.pt_chunk_enable_trace(self.h, max_steps, max_passes))

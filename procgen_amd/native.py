@@ -63,7 +63,8 @@ EXPORTS = [
     "pt_graph_swap_pass", "pt_graph_read_energies", "pt_graph_download", "pt_graph_replica_slots", "pt_graph_cost_terms",
     "pt_graph_get_stats", "pt_graph_kernel_time", "pt_graph_stream", "pt_graph_info", "pt_debug_canonical_sum",
     "pt_graph_enable_convergence", "pt_graph_check_convergence", "pt_graph_run_until_converged", "check_convergence_async",
-    "pt_geometric_ladder", "pt_swap_frequency", "pt_seed_key",
+    "pt_geometric_ladder", "pt_swap_frequency", "pt_seed_key", "pt_hash_coordinates",
+    "pt_graph_set_ladder_keys", "pt_chunk_set_ladder_keys", "pt_chunk_set_positions",
     "pt_chunk_default_config", "pt_chunk_create", "pt_chunk_destroy", "pt_chunk_upload", "pt_chunk_set_draws",
     "pt_chunk_enable_trace", "pt_chunk_read_trace", "pt_chunk_run", "pt_chunk_sync", "pt_chunk_download",
     "pt_chunk_replica_slots", "pt_chunk_cost_terms", "pt_chunk_get_stats", "pt_chunk_kernel_time",
@@ -190,6 +191,11 @@ def load():
     L.pt_swap_frequency.argtypes = [i32]
     L.pt_seed_key.restype = C.c_uint64
     L.pt_seed_key.argtypes = [C.c_char_p]
+    L.pt_hash_coordinates.restype = C.c_uint64
+    L.pt_hash_coordinates.argtypes = [C.c_uint64, i32, i32, i32]
+    L.pt_graph_set_ladder_keys.argtypes = [vp, vp]
+    L.pt_chunk_set_ladder_keys.argtypes = [vp, vp]
+    L.pt_chunk_set_positions.argtypes = [vp, vp]
     _lib = L
     return L
 
@@ -212,6 +218,10 @@ def geometric_ladder(t_min, t_max, n):
 
 def swap_frequency(n):
     return int(load().pt_swap_frequency(n))
+
+
+def hash_coordinates(base_seed: int, x: int, y: int, z: int) -> int:
+    return int(load().pt_hash_coordinates(C.c_uint64(base_seed), x, y, z))
 
 
 def seed_key(seed: str) -> int:

@@ -40,6 +40,26 @@ def test_seed_key_is_sha256_prefix():
         assert nt.seed_key(s) == struct.unpack("<Q", hashlib.sha256(s.encode()).digest()[:8])[0]
 
 
+def test_hash_coordinates_matches_the_restatement_and_a_big_integer_evaluation():
+    """DeterministicGeneration.hashCoordinates (reference src/Deterministic.fs:94-102): `uint64 x` of a negative
+    int sign-extends; three xor-multiply-shift rounds."""
+    import oracle_binding as ob
+    M = (1 << 64) - 1
+
+    def by_hand(seed, x, y, z):
+        h = seed
+        for v, c in ((x, 0xff51afd7ed558ccd), (y, 0xc4ceb9fe1a85ec53), (z, 0xff51afd7ed558ccd)):
+            h ^= ((v & M) * c) & M
+            h ^= h >> 33
+        return h
+
+    for seed in (0, 1, 42, 0xdeadbeefcafef00d, M):
+        for xyz in ((0, 0, 0), (1, 2, 3), (-1, 0, 0), (0, -7, 5), (2147483647, -2147483648, 12345), (-3, -3, -3)):
+            got = nt.hash_coordinates(seed, *xyz)
+            assert got == by_hand(seed, *xyz) == int(ob.lib().og_hash_coordinates(seed, *xyz))
+    assert nt.hash_coordinates(7, 0, 0, 0) == 7 ^ (7 >> 33)      # x = y = z = 0 leaves only the shifts
+
+
 def test_probe_call_is_harmless_without_gpu():
     # reference src/GPU.Wrappers.fs:112: parallel_tempering_step([||],[||],[||],[||],0,0,0)
     lib = nt.load()

@@ -140,3 +140,49 @@ def test_custom_weights_and_mutation_constants(gpu_lib):
     w = [1.0, 5.0, 2.0, 7.0, 3.0, 0.5, 4.0, 6.0]
     gpu = _gpu(wl, 250, 11, seed="w", weights=w)
     _assert_same(wl, gpu, 250, 11, seed="w", weights=w)
+
+
+def test_a_chunk_keyed_by_its_position_does_not_depend_on_its_place_in_the_batch(gpu_lib):
+    """Terrain.Generation.generate seeds a chunk with hashCoordinates seed x y z (reference
+    src/Terrain.Generation.fs:172-176).  With positions given, a chunk's draws depend on (seed, position) only:
+    the same chunk at two places of two different batches has the same trace, and that trace is the oracle's
+    for the key og_hash_coordinates gives."""
+    T, iters, f, seed = 4, 150, 9, "terrain-seed"
+    wl = wlm.chunk_workload("keyed", 3, T)
+    pos_a = np.array([[4, -2, 7], [0, 0, 0], [-11, 3, 5]], np.int32)
+    order_b = [2, 0, 1]                                  # the same chunks, shuffled
+    runs = []
+    for order, positions in ((list(range(3)), pos_a), (order_b, pos_a[order_b])):
+        eng = ChunkEngine(T, 3, swap_frequency=f, seed=seed)
+        try:
+            eng.upload(wl["density"][order], wl["moisture"][order], wl["temperature"][order], wl["material"][order],
+                       wl["temperatures"][order])
+            eng.set_positions(positions)
+            passes = (iters + f - 1) // f
+            eng.enable_trace(iters, passes)
+            eng.run(iters)
+            eng.sync()
+            res = eng.download()
+            res["trace"], res["swap_trace"] = eng.read_trace(iters, passes)
+            assert eng.stats()["status_bits"] == 0
+            runs.append(res)
+        finally:
+            eng.close()
+    a, b = runs
+    base = int(ob.lib().og_seed_key(seed.encode()))
+    cfg = tb.default_config(ob.SUM_CANONICAL)
+    for g in range(3):
+        gb = order_b.index(g)                            # where chunk g sits in the second batch
+        for fld in FIELDS:
+            assert np.array_equal(a["trace"][:, g * T:(g + 1) * T][fld], b["trace"][:, gb * T:(gb + 1) * T][fld]), fld
+        assert np.array_equal(a["swap_trace"][:, g], b["swap_trace"][:, gb])
+        assert np.array_equal(a["density"][g], b["density"][gb]) and np.array_equal(a["cost"][g], b["cost"][gb])
+        key = int(ob.lib().og_hash_coordinates(base, int(pos_a[g, 0]), int(pos_a[g, 1]), int(pos_a[g, 2])))
+        assert key == nt.hash_coordinates(base, *[int(v) for v in pos_a[g]])
+        o = tb.run(wl["density"][g], wl["moisture"][g], wl["temperature"][g], wl["material"][g], wl["temperatures"][g],
+                   iters, f, cfg, key=key, stream_base=0, swap_stream_id=0)
+        for fld in FIELDS:
+            assert np.array_equal(a["trace"][:, g * T:(g + 1) * T][fld], o["trace"][fld]), fld
+        assert np.array_equal(a["swap_trace"][:, g], o["swap_trace"]) and np.array_equal(a["cost"][g], o["cost"])
+    # two chunks with equal contents at different positions take different trajectories
+    assert not np.array_equal(a["trace"][:, 0:T]["a"], a["trace"][:, T:2 * T]["a"])

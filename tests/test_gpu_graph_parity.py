@@ -345,6 +345,40 @@ def test_trace_parity_injected_draws(gpu_lib):
     pu.assert_same_run(wl, gpu, orc, iters)
 
 
+def test_ladder_keys_make_a_ladder_independent_of_its_batch_index(gpu_lib):
+    """With per-ladder keys a ladder's draws depend on its key, not on where it sits in the batch: two
+    batches holding the same ladders in different order give the same traces, which are the oracle's."""
+    n, T, G, iters, f = 90, 4, 3, 200, 7
+    wl = wlm.graph_workload("keyed", n, T, G)
+    base = nt.seed_key("keyed-seed")
+    keys = np.array([nt.hash_coordinates(base, 5 * g - 3, g, -g) for g in range(G)], np.uint64)
+    order_b = [1, 2, 0]
+    runs = []
+    for order in (list(range(G)), order_b):
+        with GraphEngine(n, wl["ecap"], T, G, swap_frequency=f, seed="keyed-seed") as eng:
+            eng.upload(wl["pos"][order], wl["edges"][order], wl["ecount"][order], wl["temperatures"][order],
+                       wl["kind"][order], wl["value"][order])
+            eng.set_ladder_keys(keys[order])
+            passes = (iters + f - 1) // f
+            eng.enable_trace(iters, passes)
+            eng.run(iters)
+            res = eng.download()
+            res["trace"], res["swap_trace"] = eng.read_trace(iters, passes)
+            assert eng.stats()["status_bits"] == 0
+            runs.append(res)
+    a, b = runs
+    cfg = ob.default_config(ob.SUM_CANONICAL, ob.ALGO_OPTIMISED)
+    for g in range(G):
+        gb = order_b.index(g)
+        o = ob.run(wl["pos"][g], wl["edges"][g], wl["ecount"][g], wl["kind"][g], wl["value"][g], wl["temperatures"][g],
+                   iters, f, cfg, key=int(keys[g]), stream_base=0, swap_stream_id=0)
+        for fld in pu.TRACE_FIELDS:
+            assert np.array_equal(a["trace"][:, g * T:(g + 1) * T][fld], b["trace"][:, gb * T:(gb + 1) * T][fld]), fld
+            assert np.array_equal(a["trace"][:, g * T:(g + 1) * T][fld], o["trace"][fld]), fld
+        assert np.array_equal(a["swap_trace"][:, g], o["swap_trace"]) and np.array_equal(b["swap_trace"][:, gb], o["swap_trace"])
+        assert np.array_equal(a["cost"][g], o["cost"]) and np.array_equal(a["pos"][g], o["pos"])
+
+
 def test_perturb_only_and_custom_weights(gpu_lib):
     n, T, iters, f = 150, 4, 300, 9
     wl = wlm.graph_workload("perturb", n, T, 1)
