@@ -67,7 +67,9 @@ const char *pt_last_error_string(void);
  * (nodeCount, edgeCount, tempCount) and restart when they change.
  * Node 0 is the origin, node nodeCount-1 the terminal, every other node
  * Standard 0.0 (node values do not cross this ABI).
- * With all counts 0 it returns at once without touching the GPU state.
+ * With all counts 0 (the host's availability probe) it returns at once without touching the GPU state;
+ * pt_last_error() is then PT_ERR_NO_DEVICE when the process has no usable GPU (the host's available()
+ * can only see an exception, so a host that wants the CPU fallback in that case checks it).
  * On failure the outputs are left untouched; see pt_last_error().
  */
 void parallel_tempering_step(double *positions, int *edges, double *costs, double *temperatures,

@@ -104,8 +104,9 @@ int main(int argc, char **argv)
         double e0[1]; int e1[1];
         step(e0, e1, e0, e0, 0, 0, 0);
         step(NULL, NULL, NULL, NULL, 0, 0, 0);
-        if (last_error() != 0) FAIL("the probe reported error %d", last_error());
-        printf("probe: ok\n");
+        /* the probe computes nothing; what it can report is that the process has no GPU at all */
+        if (last_error() != 0 && !(layout_only && last_error() == PT_ERR_NO_DEVICE)) FAIL("the probe reported error %d", last_error());
+        printf("probe: ok%s\n", last_error() == PT_ERR_NO_DEVICE ? " (no GPU in this process)" : "");
     }
     /* the engine-side ABI binds and its config has the size the glue passes */
     {

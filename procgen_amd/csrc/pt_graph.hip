@@ -50,7 +50,7 @@ struct pt_graph_engine {
     SwapParams SP;
     DevBuf px, py, pz, ea, eb, et, ebuf, ecount, kind, value, origin, terminal, rowend, adj, adj4, cost, temps,
         slot_of_rep, rep_of_slot, cells, sorted, queue, bitmap, collbuf, comm, chain_u, swap_u, trace, swap_trace,
-        stats, swap_stats, status, terms, group_keys, dacc, dreach, dvis, dparent, dparscr, dlabel, dlabscr, epk,
+        stats, swap_stats, status, terms, group_keys, legacy_in, legacy_out, legacy_flag, dacc, dreach, dvis, dparent, dparscr, dlabel, dlabscr, epk,
         dparent32, dparscr32, bvis, bjmp, bdist, bcomm,
         conv_hist, conv_swaps, conv_swap_total, conv_out;
     int conv_window = 0;            // 0: convergence monitoring off
@@ -134,11 +134,20 @@ int launch_steps(pt_graph_engine *e, long long step0, int nsteps)
     // The incremental kernels hand out discovery labels from a 32-bit counter that only grows (by at
     // most one per edge looked at in a step).  Long before it can wrap, the state they continue from is
     // rebuilt from scratch by the init kernel: same cost, same sums, same reached sets bit for bit, a
-    // fresh search tree with labels below N.
-    if ((e->delta_mode || e->big_mode) && e->steps_since_init > 0 && e->steps_since_init + nsteps > e->relabel_every) {
-        int rc = launch_init(e, e->P, 1);
-        if (rc) return rc;
-        e->steps_since_init = 0;
+    // fresh search tree with labels below N.  No launch runs more than relabel_every steps on one set
+    // of labels: a longer request is cut into pieces with a rebuild between them.
+    if (e->delta_mode || e->big_mode) {
+        if (e->steps_since_init >= e->relabel_every) {
+            int rc = launch_init(e, e->P, 1);
+            if (rc) return rc;
+            e->steps_since_init = 0;
+        }
+        const long long room = e->relabel_every - e->steps_since_init;
+        if (nsteps > room) {
+            int rc = launch_steps(e, step0, (int)room);
+            if (rc) return rc;
+            return launch_steps(e, step0 + room, nsteps - (int)room);
+        }
     }
     e->steps_since_init += nsteps;
     hipEvent_t a = nullptr, b = nullptr;
@@ -459,18 +468,28 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         delete e;
         return pt::set_error(PT_ERR_INVALID_ARGUMENT, "cluster_size must be 0..4 (0..16 for replicas held in global memory)");
     }
-    // a census launch: are `blocks` workgroups with this LDS footprint resident all at once?
+    // A census launch: are `blocks` workgroups with this LDS footprint resident all at once?  It runs on the
+    // engine's own stream and waits for that stream only, so it does not stall other engines of the process;
+    // what it observes is the device as it is now -- a clustered engine needs the CUs it was promised while it
+    // runs (another engine's long kernel can leave a clustered grid partly resident, and the launch then ends
+    // with PT_ERR_CLUSTER_TIMEOUT, reported by the next call that waits for the stream).
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        delete e;
+        return pt::set_error(PT_ERR_HIP, "cannot create the engine's stream");
+    }
     auto census = [&](unsigned blocks) -> bool {
         DevBuf probe;
         unsigned init[2] = {0u, 1u}, res[2] = {0u, 0u};
         if (probe.alloc(sizeof init) != hipSuccess) { (void)hipGetLastError(); return false; }
-        bool ok = hipMemcpy(probe.p, init, sizeof init, hipMemcpyHostToDevice) == hipSuccess;
+        bool ok = hipMemcpyAsync(probe.p, init, sizeof init, hipMemcpyHostToDevice, e->stream) == hipSuccess;
         if (ok && lds > 64 * 1024)
             ok = hipFuncSetAttribute((const void *)pt_census_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
         if (ok) {
-            hipLaunchKernelGGL(pt_census_kernel, dim3(blocks), dim3(64), lds, 0, probe.as<unsigned>(), probe.as<unsigned>() + 1, blocks);
-            ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
-                 hipMemcpy(res, probe.p, sizeof res, hipMemcpyDeviceToHost) == hipSuccess;
+            hipLaunchKernelGGL(pt_census_kernel, dim3(blocks), dim3(64), lds, e->stream, probe.as<unsigned>(), probe.as<unsigned>() + 1, blocks);
+            ok = hipGetLastError() == hipSuccess &&
+                 hipMemcpyAsync(res, probe.p, sizeof res, hipMemcpyDeviceToHost, e->stream) == hipSuccess &&
+                 hipStreamSynchronize(e->stream) == hipSuccess;
         }
         if (!ok) (void)hipGetLastError();
         return ok && res[0] == blocks && res[1] == 1u;
@@ -509,21 +528,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         C = want;
         // census: shrink the cluster until a grid of that many workgroups (same LDS footprint) is
         // observed to be resident all at once
-        while (C > 1) {
-            DevBuf probe;
-            unsigned init[2] = {0u, 1u}, res[2] = {0u, 0u};
-            if (probe.alloc(sizeof init) != hipSuccess) { (void)hipGetLastError(); C = 1; break; }
-            const unsigned blocks = (unsigned)(rows * C);
-            bool ok = hipMemcpy(probe.p, init, sizeof init, hipMemcpyHostToDevice) == hipSuccess;
-            if (ok && lds > 64 * 1024)
-                ok = hipFuncSetAttribute((const void *)pt_census_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-            if (ok) {
-                hipLaunchKernelGGL(pt_census_kernel, dim3(blocks), dim3(64), lds, 0, probe.as<unsigned>(), probe.as<unsigned>() + 1, blocks);
-                ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
-                     hipMemcpy(res, probe.p, sizeof res, hipMemcpyDeviceToHost) == hipSuccess;
-            }
-            if (ok && res[0] == blocks && res[1] == 1u) break;
-            (void)hipGetLastError();
+        while (C > 1 && !census((unsigned)(rows * C))) {
             if (cfg->cluster_size > 1) {
                 delete e;
                 return pt::set_error(PT_ERR_INVALID_ARGUMENT, "cluster_size: that many workgroups are not co-resident on this device");
@@ -577,7 +582,6 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         A(e->bdist, sizeof(float) * (size_t)R * N);
         if (e->CB > 1) A(e->bcomm, sizeof(BigComm) * (size_t)R);
     }
-    if (herr == hipSuccess) herr = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (herr == hipSuccess && e->delta_mode && e->delta_lds_bytes > 64 * 1024)
         herr = hipFuncSetAttribute(e->ept == 48 ? (const void *)pt_graph_delta_kernel<48, 32, 512>
                                    : e->ept == 32 ? (const void *)pt_graph_delta_kernel<32, 16, 768>
@@ -1109,6 +1113,149 @@ int pt_graph_info(pt_graph_engine *e, pt_graph_info_rec *out)
     out->swap_frequency = e->f;
     return PT_OK;
 }
+
+}  // extern "C"
+
+// ---- the drop-in entry points' iteration on resident chains ----------------------------------------------
+// The unchanged host calls parallel_tempering_step once per iteration and passes the array the previous
+// call filled (reference src/GPU.Wrappers.fs:314-323).  Uploading it, re-evaluating every chain's cost and
+// downloading everything per call is what the call pattern suggests and costs milliseconds; instead the
+// chains stay resident, the caller's array is copied to the device as it is (no host-side conversion), one
+// kernel checks that it still equals the resident chains (slot order, after the float conversion a fresh
+// upload would apply) and only a caller that edited its positions pays for a reload and a fresh cost
+// evaluation.  Everything the iteration does is addressed by temperature slot, so resident chains in
+// permuted order give the same bits as freshly uploaded ones in slot order.
+namespace {
+
+template <class Real>
+__global__ void legacy_compare_kernel(const Real *in, const float *px, const float *py, const float *pz, const int *rep_of_slot,
+                                      int T, int N, int *mismatch)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (long long)T * N) return;
+    const int s = (int)(k / N), i = (int)(k - (long long)s * N);
+    const size_t at = (size_t)rep_of_slot[s] * N + i;
+    // bit patterns: a NaN never equals the resident value and so forces the reload that reports it
+    const bool same = __float_as_uint((float)in[3 * k]) == __float_as_uint(px[at]) &&
+                      __float_as_uint((float)in[3 * k + 1]) == __float_as_uint(py[at]) &&
+                      __float_as_uint((float)in[3 * k + 2]) == __float_as_uint(pz[at]);
+    if (!same) *mismatch = 1;
+}
+
+template <class Real>
+__global__ void legacy_load_kernel(const Real *in, float *px, float *py, float *pz, int T, int N)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (long long)T * N) return;
+    px[k] = (float)in[3 * k]; py[k] = (float)in[3 * k + 1]; pz[k] = (float)in[3 * k + 2];     // chain t = replica t = slot t
+}
+
+// The chains in slot order in the caller's width, plus the list of the nodes whose three values differ (as
+// bits) from what the caller's array holds now: after an ordinary iteration that is at most one node per
+// chain, and only those need to travel back.  changed[0] counts them (entries beyond `cap` are dropped:
+// the host then takes the whole array).
+template <class Real> struct LegacyChange { long long k; Real x, y, z; };
+__device__ __forceinline__ bool same_bits(float a, float b) { return __float_as_uint(a) == __float_as_uint(b); }
+__device__ __forceinline__ bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
+template <class Real>
+__global__ void legacy_store_kernel(Real *out, Real *cost_out, const Real *in, const float *px, const float *py, const float *pz,
+                                    const double *cost, const int *rep_of_slot, int T, int N, int *changed,
+                                    LegacyChange<Real> *list, int cap)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (long long)T * N) return;
+    const int s = (int)(k / N), i = (int)(k - (long long)s * N);
+    const size_t at = (size_t)rep_of_slot[s] * N + i;
+    const Real x = (Real)px[at], y = (Real)py[at], z = (Real)pz[at];
+    out[3 * k] = x; out[3 * k + 1] = y; out[3 * k + 2] = z;
+    if (i == 0) cost_out[s] = (Real)cost[rep_of_slot[s]];
+    if (!same_bits(x, in[3 * k]) || !same_bits(y, in[3 * k + 1]) || !same_bits(z, in[3 * k + 2])) {
+        const int slot = atomicAdd(changed, 1);
+        if (slot < cap) { list[slot].k = k; list[slot].x = x; list[slot].y = y; list[slot].z = z; }
+    }
+}
+
+template <class Real>
+int legacy_iteration(pt_graph_engine *e, Real *positions, Real *costs, long long call_index, bool positions_are_new)
+{
+    const int T = e->T, N = e->N;
+    const size_t cells = (size_t)T * N, bytes = sizeof(Real) * 3 * cells;
+    hipStream_t st = e->stream;
+    if (e->legacy_in.bytes < bytes) PT_HIP_TRY(e->legacy_in.alloc(bytes));
+    if (e->legacy_out.bytes < bytes + sizeof(Real) * (size_t)T) PT_HIP_TRY(e->legacy_out.alloc(bytes + sizeof(Real) * (size_t)T));
+    constexpr int CAP = 4096;               // changed nodes sent back one by one; more than that and the whole array goes
+    if (!e->legacy_flag.p) PT_HIP_TRY(e->legacy_flag.alloc(2 * sizeof(int) + sizeof(LegacyChange<double>) * CAP));
+    int *d_changed = e->legacy_flag.as<int>() + 1;
+    LegacyChange<Real> *d_list = (LegacyChange<Real> *)(e->legacy_flag.as<int>() + 2);
+    const unsigned threads = 256, blocks = (unsigned)((cells + threads - 1) / threads);
+    Real *d_in = e->legacy_in.as<Real>(), *d_out = e->legacy_out.as<Real>();
+    PT_HIP_TRY(hipMemcpyAsync(d_in, positions, bytes, hipMemcpyHostToDevice, st));
+    int reload = positions_are_new ? 1 : 0;
+    if (!reload) {
+        PT_HIP_TRY(hipMemsetAsync(e->legacy_flag.p, 0, sizeof(int), st));
+        hipLaunchKernelGGL(legacy_compare_kernel<Real>, dim3(blocks), dim3(threads), 0, st, d_in, e->px.as<float>(), e->py.as<float>(),
+                           e->pz.as<float>(), e->rep_of_slot.as<int>(), T, N, e->legacy_flag.as<int>());
+        PT_HIP_TRY(hipGetLastError());
+        PT_HIP_TRY(hipMemcpyAsync(&reload, e->legacy_flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        PT_HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (reload) {
+        // the caller's chains, as a fresh upload would place them: chain t in replica t in slot t, costs from scratch
+        std::vector<int> ident((size_t)T);
+        for (int t = 0; t < T; t++) ident[(size_t)t] = t;
+        hipLaunchKernelGGL(legacy_load_kernel<Real>, dim3(blocks), dim3(threads), 0, st, d_in, e->px.as<float>(), e->py.as<float>(),
+                           e->pz.as<float>(), T, N);
+        PT_HIP_TRY(hipGetLastError());
+        PT_HIP_TRY(hipMemcpyAsync(e->slot_of_rep.p, ident.data(), sizeof(int) * (size_t)T, hipMemcpyHostToDevice, st));
+        PT_HIP_TRY(hipMemcpyAsync(e->rep_of_slot.p, ident.data(), sizeof(int) * (size_t)T, hipMemcpyHostToDevice, st));
+        PT_HIP_TRY(hipStreamSynchronize(st));           // `ident` leaves scope
+        int rc = launch_init(e, e->P, 1);
+        if (rc) return rc;
+        e->steps_since_init = 0;
+    }
+    e->step = call_index;
+    { int rc = run_steps(e, 1); if (rc) return rc; }
+    PT_HIP_TRY(hipMemsetAsync(d_changed, 0, sizeof(int), st));
+    hipLaunchKernelGGL(legacy_store_kernel<Real>, dim3(blocks), dim3(threads), 0, st, d_out, d_out + 3 * cells, (const Real *)d_in,
+                       e->px.as<float>(), e->py.as<float>(), e->pz.as<float>(), e->cost.as<double>(), e->rep_of_slot.as<int>(), T, N,
+                       d_changed, d_list, CAP);
+    PT_HIP_TRY(hipGetLastError());
+    // the outputs are written only once the device reports no failure: first the costs, the count and the status ...
+    std::vector<Real> hc((size_t)T);
+    int changed = 0;
+    PT_HIP_TRY(hipMemcpyAsync(hc.data(), d_out + 3 * cells, sizeof(Real) * (size_t)T, hipMemcpyDeviceToHost, st));
+    PT_HIP_TRY(hipMemcpyAsync(&changed, d_changed, sizeof(int), hipMemcpyDeviceToHost, st));
+    PT_HIP_TRY(hipStreamSynchronize(st));
+    { int rc = device_status(e->status.p); if (rc) return rc; }
+    // ... then the positions: the few nodes that changed, or (first call of a job, swap passes) the whole array
+    if (changed <= CAP) {
+        std::vector<LegacyChange<Real>> list((size_t)changed);
+        if (changed) {
+            PT_HIP_TRY(hipMemcpyAsync(list.data(), d_list, sizeof(LegacyChange<Real>) * (size_t)changed, hipMemcpyDeviceToHost, st));
+            PT_HIP_TRY(hipStreamSynchronize(st));
+        }
+        for (const LegacyChange<Real> &c : list) { positions[3 * c.k] = c.x; positions[3 * c.k + 1] = c.y; positions[3 * c.k + 2] = c.z; }
+    } else {
+        PT_HIP_TRY(hipMemcpyAsync(positions, d_out, bytes, hipMemcpyDeviceToHost, st));
+        PT_HIP_TRY(hipStreamSynchronize(st));
+    }
+    for (int t = 0; t < T; t++) costs[t] = hc[(size_t)t];
+    return PT_OK;
+}
+
+}  // namespace
+
+int pt_graph_legacy_iteration(pt_graph_engine *e, void *positions, void *costs, int real_bytes, long long call_index,
+                              bool positions_are_new)
+{
+    if (!e || !e->uploaded || e->G != 1 || e->Tl != e->T) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "not a whole single ladder");
+    std::lock_guard<std::mutex> lock(e->mu);
+    DeviceGuard guard(e->device);
+    if (real_bytes == 8) return legacy_iteration<double>(e, (double *)positions, (double *)costs, call_index, positions_are_new);
+    return legacy_iteration<float>(e, (float *)positions, (float *)costs, call_index, positions_are_new);
+}
+
+extern "C" {
 
 #ifdef PT_STAMPS
 // diagnostic build only: read (and clear) the per-phase cycle totals, [4096][16]

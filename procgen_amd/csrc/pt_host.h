@@ -20,6 +20,12 @@ int device_count();
 
 }  // namespace pt
 
+struct pt_graph_engine;
+// One iteration of the drop-in entry points on an engine that keeps the chains resident between calls (not
+// part of the C ABI): see pt_graph.hip.
+int pt_graph_legacy_iteration(pt_graph_engine *e, void *positions, void *costs, int real_bytes, long long call_index,
+                              bool positions_are_new);
+
 #define PT_HIP_TRY(expr)                                                                         \
     do {                                                                                         \
         hipError_t _e = (expr);                                                                  \

@@ -60,8 +60,7 @@ class Wrappers:
         try:
             lib = nt.load()
             lib.parallel_tempering_step(None, None, None, None, 0, 0, 0)
-            import torch
-            return bool(torch.cuda.is_available())
+            return lib.pt_last_error() == 0             # PT_ERR_NO_DEVICE: the process has no usable GPU
         except Exception:
             return False
 

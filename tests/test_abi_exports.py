@@ -64,4 +64,6 @@ def test_probe_call_is_harmless_without_gpu():
     # reference src/GPU.Wrappers.fs:112: parallel_tempering_step([||],[||],[||],[||],0,0,0)
     lib = nt.load()
     lib.parallel_tempering_step(None, None, None, None, 0, 0, 0)
-    assert lib.pt_last_error() == 0
+    # nothing ran; the only thing the probe reports is whether the process has a GPU at all
+    import torch
+    assert lib.pt_last_error() == (0 if torch.cuda.is_available() else 2)

@@ -224,3 +224,54 @@ def test_optimize_until_convergence_wrapper(gpu_lib):
         ed = np.array([(a, b) for a, b, _ in c.State.Edges], np.int32).reshape(-1, 2)
         want = ob.cost(c.State.Positions, ed, ob.default_kinds(n), np.zeros(n), cfg).total
         assert c.Cost == want
+
+
+@pytest.mark.parametrize("T", [64, 65, 66, 129, 200])
+def test_long_ladders_swap_pass_and_history(gpu_lib, T):
+    """Ladders longer than a wave: the swap pass takes the pairs 64 at a time and carries the state that
+    bubbles up from one batch into the next.  Injected swap draws force refusals on the first and the last
+    pair of a batch and unbroken runs of swaps across the batch boundary; every decision, the final slot
+    map, the costs and the convergence statistics equal the oracle's."""
+    import parity_util as pu
+    n, G, f, iters, window = 12, 2, 3, 45, 20
+    wl = wlm.graph_workload("long-ladder", n, T, G, edge_headroom=6.0)
+    wl["temperatures"][:] = nt.geometric_ladder(0.3, 9.0, T)
+    rng = np.random.default_rng(T)
+    passes = (iters + f - 1) // f
+    chain_u = rng.random((G, T, iters, nt.DRAWS_PER_STEP))
+    swap_u = rng.random((G, passes, T - 1))
+    never, always = np.nextafter(1.0, 0.0), 0.0
+    for p in range(passes):
+        mode = p % 5
+        if mode == 0:
+            swap_u[:, p, :] = always                    # one state carried from the hottest slot to the coldest
+        elif mode == 1:
+            swap_u[:, p, :] = always
+            swap_u[:, p, 0] = never                      # refusal on the first pair of the first batch
+            if T > 64:
+                swap_u[:, p, 63] = never                 # ... on the last pair of the first batch
+        elif mode == 2 and T > 65:
+            swap_u[:, p, :] = never
+            swap_u[:, p, 60:min(70, T - 1)] = always     # a run of swaps across the batch boundary
+        elif mode == 3 and T > 65:
+            swap_u[:, p, 64] = never                     # refusal on the first pair of the second batch
+    with GraphEngine(n, wl["ecap"], T, G, swap_frequency=f, rng_mode=nt.RNG_INJECTED) as eng:
+        eng.upload(wl["pos"], wl["edges"], wl["ecount"], wl["temperatures"], wl["kind"], wl["value"])
+        eng.set_draws(chain_u, swap_u)
+        eng.enable_trace(iters, passes)
+        eng.enable_convergence(window)
+        eng.run(20)
+        eng.run(iters - 20)
+        got = eng.check_convergence(0.25, iteration=iters)
+        gpu = eng.download()
+        gpu["trace"], gpu["swap_trace"] = eng.read_trace(iters, passes)
+        gpu["stats"], gpu["slots"], gpu["terms"] = eng.stats(), eng.replica_slots(), eng.cost_terms()
+    orc = pu.oracle_run(wl, iters, f, chain_u=chain_u, swap_u=swap_u)
+    pu.assert_same_run(wl, gpu, orc, iters)
+    for g in range(G):
+        assert np.array_equal(gpu["slots"][g], pu.slots_after(orc[g]["swap_trace"], T))
+        h = ob.ConvHistory(T, window)
+        for row, outs in history_rows(gpu["trace"], gpu["swap_trace"], g, T, f, 0, iters):
+            h.update(row, outs)
+        same(got[g], h.check(iters, 0.25), f"ladder {g}")
+    assert gpu["swap_trace"].any() and not gpu["swap_trace"].all()

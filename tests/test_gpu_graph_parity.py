@@ -260,6 +260,19 @@ def test_periodic_rebuild_of_the_search_state_changes_nothing(gpu_lib, flags, mo
     assert len(np.unique(gpu["trace"]["reach0"])) > 3
 
 
+@pytest.mark.parametrize("flags", [0, nt.FLAG_STREAMING_INCREMENTAL], ids=["incremental", "incremental-global"])
+def test_rebuild_inside_a_swap_interval(gpu_lib, flags, monkeypatch):
+    """A swap interval longer than the rebuild period (as at 10^6 nodes, where the interval is 2000 steps and the
+    period about 800): the launch is cut into pieces with a rebuild between them."""
+    monkeypatch.setenv("PROCGEN_PT_RELABEL_EVERY", "11")
+    wl = _topology_case("near-tree")
+    iters, f = 300, 50
+    gpu = pu.gpu_run(wl, iters, f, seed="rebuild-inside", chunks=[120, 180], flags=flags)
+    orc = pu.oracle_run(wl, iters, f, seed="rebuild-inside")
+    pu.assert_same_run(wl, gpu, orc, iters)
+    assert len(np.unique(gpu["trace"]["reach0"])) > 3
+
+
 def test_trace_parity_many_small_replicas(gpu_lib):
     """More replicas than twice the CUs: the engine then picks its smallest workgroup."""
     n, T, G, iters, f = 300, 16, 40, 60, 7

@@ -115,3 +115,51 @@ def test_dispatch_takes_the_gpu_path_above_thresholds(gpu_lib):
     assert len(chains) == T and all(c.Cost == 1.5 and c.AcceptanceRate == 0.5 for c in chains)
     o = _oracle(wl, 20, nt.swap_frequency(n))
     assert np.array_equal(np.stack([c.State.Positions for c in chains]), o["pos"])
+
+
+def test_resident_chains_and_a_caller_that_edits_its_positions(gpu_lib):
+    """The entry keeps the chains on the device between calls and checks that the caller's array still holds
+    them; a caller that edits positions between two calls gets exactly what a fresh upload of the edited
+    array gives."""
+    n, T = 80, 4
+    f = nt.swap_frequency(n)
+    assert f == 17
+    wl, _ = _job(n, T, "edit")
+    e = int(wl["ecount"][0, 0])
+    pos = wl["pos"][0].astype(np.float64).reshape(-1).copy()
+    edges = wl["edges"][0, 0].reshape(-1).astype(np.int32).copy()
+    costs = np.zeros(T, np.float64)
+    temps = wl["temperatures"][0].astype(np.float64).copy()
+
+    def call(k):
+        for _ in range(k):
+            gpu_lib.parallel_tempering_step(nt.ptr(pos), nt.ptr(edges), nt.ptr(costs), nt.ptr(temps), n, e, T)
+            assert gpu_lib.pt_last_error() == 0, gpu_lib.pt_last_error_string()
+
+    gpu_lib.parallel_tempering_reset()
+    call(12)                                            # calls 0..11 (a swap pass after call 0)
+    cfg = ob.default_config(ob.SUM_CANONICAL, ob.ALGO_OPTIMISED, ob.MUT_PERTURB_ONLY)
+    key = int(ob.lib().og_seed_key(SEED.encode()))
+    o1 = ob.run(wl["pos"][0], wl["edges"][0], wl["ecount"][0], wl["kind"][0], wl["value"][0], temps, 12, f, cfg, key=key,
+                trace=False)
+    assert np.array_equal(pos.reshape(T, n, 3).astype(np.float32), o1["pos"]) and np.array_equal(costs, o1["cost"])
+    # the caller moves one node of chain 2 and stretches chain 0
+    p3 = pos.reshape(T, n, 3)
+    p3[2, 5] += 0.25
+    p3[0] *= 1.01
+    edited = p3.astype(np.float32)
+    call(4)                                             # calls 12..15: no swap pass among them
+    o2 = ob.run(edited, o1["edges"], o1["ecount"], wl["kind"][0], wl["value"][0], temps, 4, f, cfg, key=key, trace=False,
+                first_step=12)
+    assert np.array_equal(pos.reshape(T, n, 3).astype(np.float32), o2["pos"]) and np.array_equal(costs, o2["cost"])
+    # a caller that changes the ladder or the topology is followed as well
+    temps[:] = temps * 1.5
+    edges2 = edges.copy()
+    edges2[0:2] = [3, 9] if not (edges[0] == 3 and edges[1] == 9) else [4, 9]
+    before = pos.reshape(T, n, 3).astype(np.float32).copy()
+    gpu_lib.parallel_tempering_step(nt.ptr(pos), nt.ptr(edges2), nt.ptr(costs), nt.ptr(temps), n, e, T)
+    assert gpu_lib.pt_last_error() == 0
+    ed = np.tile(edges2.reshape(1, e, 2), (T, 1, 1))
+    o3 = ob.run(before, ed, o1["ecount"], wl["kind"][0], wl["value"][0], temps, 1, f, cfg, key=key, trace=False, first_step=16)
+    assert np.array_equal(pos.reshape(T, n, 3).astype(np.float32), o3["pos"]) and np.array_equal(costs, o3["cost"])
+    gpu_lib.parallel_tempering_reset()

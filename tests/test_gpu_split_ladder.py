@@ -17,8 +17,10 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("flags,cluster", [pytest.param(0, 0, id="incremental"), pytest.param(nt.FLAG_FULL_EVALUATION, 0, id="full"),
                                            pytest.param(nt.FLAG_STREAMING_INCREMENTAL, 1, id="streaming"),
                                            pytest.param(nt.FLAG_STREAMING_INCREMENTAL, 3, id="streaming-cluster")])
-@pytest.mark.parametrize("n,Tl,parts,iters,f", [(60, 6, 2, 150, 9), (300, 8, 4, 120, 34)])
+@pytest.mark.parametrize("n,Tl,parts,iters,f", [(60, 6, 2, 150, 9), (300, 8, 4, 120, 34), (20, 130, 2, 60, 4)])
 def test_split_ladder_matches_whole_ladder(gpu_lib, n, Tl, parts, iters, f, flags, cluster):
+    if cluster > 1 and Tl * cluster > 256:
+        pytest.skip("that many workgroups cannot be resident at once: the engine refuses the configuration")
     wl = wlm.graph_workload("split-gpu", n, Tl, 1, edge_headroom=3.0, index=n)
     seed = f"split-{n}"
     whole = pu.gpu_run(wl, iters, f, seed=seed, trace=False, flags=flags, cluster_size=cluster)
