@@ -78,6 +78,14 @@ __device__ __forceinline__ void fx_add_small_nonneg(fx128 &acc, double t)
     acc.lo = l;
 }
 
+// trunc(t * 2^64) for 0 <= t < 2^32, without a branch (the caller vouches for the range)
+__device__ __forceinline__ fx128 fx_from_small_nonneg(double t)
+{
+    fx128 r = fx_zero();
+    fx_add_small_nonneg(r, t);
+    return r;
+}
+
 // sqrtf for a normal x well inside the exponent range, correctly rounded: the hardware's
 // approximation (1 ulp) moved to a neighbour when the residual asks for it.
 __device__ __forceinline__ float sqrt_rn_midrange(float x)
