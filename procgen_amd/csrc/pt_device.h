@@ -98,6 +98,11 @@ __device__ __forceinline__ float sqrt_rn_midrange(float x)
     return r;
 }
 
+// exp as a real call.  Inlined into a long step loop, the eleven polynomial coefficients of the library's exp
+// become loop-invariant register pairs, get spilled under register pressure, and every evaluation then waits for
+// nine scratch loads one after the other; behind a call they are immediates again.
+__device__ __attribute__((noinline)) double exp_outlined(double x) { return exp(x); }
+
 // nearest double (ties to even) of a * 2^-64
 __device__ __forceinline__ double fx_to_double(fx128 a)
 {

@@ -47,6 +47,29 @@ template <int OP> __global__ void k(double *out, unsigned long long *cyc, double
                             asm volatile("v_cmp_gt_f64 vcc, %0, %1" :: "v"(a1), "v"(a0) : "vcc"); asm volatile("v_cmp_gt_f64 vcc, %0, %1" :: "v"(a3), "v"(a2) : "vcc"); }
             if (OP == 13) { asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(u0) : "v"(u1)); asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(u2) : "v"(u3));
                             asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(u1) : "v"(u0)); asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(u3) : "v"(u2)); }
+            if (OP == 15) { asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(a0) : "v"(a1)); asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(a2) : "v"(a3));
+                            asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(a1) : "v"(a0)); asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(a3) : "v"(a2)); }
+            if (OP == 16) { asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(f0) : "v"(f1)); asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(f2) : "v"(f3));
+                            asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(f1) : "v"(f0)); asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(f3) : "v"(f2)); }
+            if (OP == 17) { asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a0) : "v"(a1)); asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a2) : "v"(a3));
+                            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a1) : "v"(a0)); asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a3) : "v"(a2)); }
+            if (OP == 18) { asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(u0) : "v"(u1), "v"(u2)); asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(u2) : "v"(u3), "v"(u0));
+                            asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(u1) : "v"(u0), "v"(u3)); asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(u3) : "v"(u2), "v"(u1)); }
+            if (OP == 19) { asm volatile("v_ldexp_f64 %0, %0, 32" : "+v"(a0)); asm volatile("v_ldexp_f64 %0, %0, 32" : "+v"(a2));
+                            asm volatile("v_ldexp_f64 %0, %0, 32" : "+v"(a1)); asm volatile("v_ldexp_f64 %0, %0, 32" : "+v"(a3)); }
+            if (OP == 20) { asm volatile("v_cmp_lt_u64 vcc, %0, %1" :: "v"(q0), "v"(q1) : "vcc"); asm volatile("v_cmp_lt_u64 vcc, %0, %1" :: "v"(q2), "v"(q3) : "vcc");
+                            asm volatile("v_cmp_lt_u64 vcc, %0, %1" :: "v"(q1), "v"(q0) : "vcc"); asm volatile("v_cmp_lt_u64 vcc, %0, %1" :: "v"(q3), "v"(q2) : "vcc"); }
+            if (OP == 21) { asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(u0) : "v"(u1) : "vcc"); asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(u2) : "v"(u3) : "vcc");
+                            asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(u1) : "v"(u0) : "vcc"); asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(u3) : "v"(u2) : "vcc"); }
+            if (OP == 22) { asm volatile("v_cmp_ge_f32 vcc, %0, %1" :: "v"(f0), "v"(f1) : "vcc"); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(f2) : "v"(f3) : "vcc");
+                            asm volatile("v_cmp_ge_f32 vcc, %0, %1" :: "v"(f1), "v"(f0) : "vcc"); asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(f3) : "v"(f2) : "vcc"); }
+            if (OP == 23) { asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(a0) : "v"(a1), "v"(a2), "v"(a3)); asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(a1) : "v"(a2), "v"(a3), "v"(a0));
+                            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(a2) : "v"(a3), "v"(a0), "v"(a1)); asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(a3) : "v"(a0), "v"(a1), "v"(a2)); }
+            if (OP == 24) { asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(a0) : "v"(a1), "v"(a2), "v"(a3)); asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(a1) : "v"(a2), "v"(a3), "v"(a0));
+                            asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(a2) : "v"(a3), "v"(a0), "v"(a1)); asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(a3) : "v"(a0), "v"(a1), "v"(a2)); }
+            if (OP == 25) { asm volatile("v_readlane_b32 s20, %0, 3" :: "v"(u0) : "s20"); asm volatile("v_readlane_b32 s21, %0, 5" :: "v"(u1) : "s21");
+                            asm volatile("v_readlane_b32 s22, %0, 7" :: "v"(u2) : "s22"); asm volatile("v_readlane_b32 s23, %0, 9" :: "v"(u3) : "s23"); }
+            if (OP == 26) { asm volatile("v_pk_mul_f32 %0, %0, %2\n v_add_f64 %1, %1, %3" : "+v"(a0), "+v"(a2) : "v"(a1), "v"(a3)); asm volatile("v_sqrt_f32 %0, %2\n v_cvt_f64_f32 %1, %3" : "=v"(f0), "=v"(a1) : "v"(f1), "v"(f2)); }
             if (OP == 14) { asm volatile("v_min_u32 %0, %0, %1" : "+v"(u0) : "v"(u1)); asm volatile("v_min_u32 %0, %0, %1" : "+v"(u2) : "v"(u3));
                             asm volatile("v_min_u32 %0, %0, %1" : "+v"(u1) : "v"(u0)); asm volatile("v_min_u32 %0, %0, %1" : "+v"(u3) : "v"(u2)); }
         }
@@ -60,7 +83,7 @@ template <int OP> void run(const char *name)
 {
     double *out; unsigned long long *cyc;
     hipMalloc(&out, 1024 * 8); hipMalloc(&cyc, 8);
-    for (int waves : {1, 4, 8, 16}) {
+    for (int waves : {1, 4, 8, 12, 16}) {
         hipLaunchKernelGGL(k<OP>, dim3(1), dim3(64 * waves), 0, 0, out, cyc, 1.5);
         hipDeviceSynchronize();
         unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
@@ -74,6 +97,9 @@ int main()
 {
     run<7>("v_add_f32"); run<14>("v_min_u32"); run<11>("v_pk_mul_f32"); run<0>("v_add_f64"); run<1>("v_mul_f64"); run<10>("v_fma_f64");
     run<12>("v_cmp_gt_f64"); run<2>("v_trunc_f64"); run<3>("v_cvt_u32_f64"); run<4>("v_cvt_f64_u32"); run<5>("v_cvt_f64_f32");
+    run<15>("v_pk_fma_f32"); run<17>("v_pk_add_f32"); run<16>("v_fma_f32"); run<18>("v_min3_u32");
+    run<19>("v_ldexp_f64"); run<20>("v_cmp_lt_u64"); run<21>("v_add(c)_co_u32"); run<22>("v_cmp+cndmask"); run<23>("v_pk_fma 3src"); run<24>("v_fma_f64 3src");
+    run<25>("v_readlane"); run<26>("mix pk/f64/sqrt/cvt");
     run<6>("v_sqrt_f32"); run<8>("v_lshlrev_b64"); run<9>("v_lshl_add_u64"); run<13>("v_mov_b32_dpp");
     return 0;
 }

@@ -68,9 +68,9 @@ def main():
                 print(f"  {name:18s} mean {st[:, k].mean() / iters:9.0f} cyc  {100 * st[:, k].sum() / tot.sum():5.1f}%"
                       f"   slowest replica {st[np.argmax(tot), k] / iters:9.0f}")
     if buf[2048:2048 + 64].sum() > 0:
-        print('per-wave cycles from barrier 1 to the end of pass 1 (mean over replicas):')
-        print('  to accumulate done:', np.round(buf[2048:2048 + R].astype(np.float64).mean(axis=0) / iters).astype(int).tolist())
-        print('  to loop+rare done :', np.round(buf[3072:3072 + R].astype(np.float64).mean(axis=0) / iters).astype(int).tolist())
+        print('per-wave cycles (mean over replicas), fine stamps build:')
+        print('  pass 1, from its start to its sums added:', np.round(buf[3072:3072 + R].astype(np.float64).mean(axis=0) / iters).astype(int).tolist())
+        print('  pass 2, from the barrier to its sums added:', np.round(buf[2048:2048 + R].astype(np.float64).mean(axis=0) / iters).astype(int).tolist())
     eng.close()
 
 
