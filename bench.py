@@ -400,6 +400,18 @@ def main():
                                      "frac_of_peak_issue": lane_instr / (FP32_VALU_PEAK_TFLOPS * 1e12 / 2.0),
                                      "note": "rocprofv3 --pmc SQ_INSTS_* of one launch (profiles/pmc_sq.json) over this run's "
                                              "launch time; 64 of 256 CUs hold a replica"}
+                    # what the SIMDs that hold a replica could issue, as measured on this chip (scripts/instr_rate.hip: with
+                    # every wave of a SIMD timed to its end, a SIMD retires one packed-fp32 / fp64 / integer / DPP instruction
+                    # per 4.4 s_memtime ticks, one plain fp32 instruction per 3.0; the counter runs at 1.42 ticks per ns)
+                    simds = 4.0 * min(R * G, 256)
+                    per_simd = sq["SQ_INSTS_VALU"] / launch_s / simds
+                    cap = 1.42e9 / 4.4
+                    measured_valu["issue_on_simds_in_use"] = {
+                        "valu_wave_instructions_per_s_per_simd": per_simd, "measured_capacity_per_s_per_simd": cap,
+                        "frac": per_simd / cap,
+                        "note": "VALU wave-instructions per second on each of the 256 SIMDs of the 64 CUs that hold a replica, against "
+                                "the rate at which one SIMD retires this instruction mix when saturated (microbenchmark, "
+                                "scripts/instr_rate.hip); the serial stretches of a step (one wave) are inside the time"}
                 except (OSError, ValueError, KeyError):
                     pass
             roofline = dict(common, bound="valu", achieved=valu, peak=FP32_VALU_PEAK_TFLOPS, unit="TFLOP/s",

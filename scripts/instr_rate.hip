@@ -1,6 +1,6 @@
 // Issue cost of a few gfx950 vector instructions (diagnostic): one workgroup of W waves on one CU
-// runs a long dependent-free stream of one instruction; cycles per wave-instruction per SIMD follow
-// from s_memtime.  Build: hipcc --offload-arch=gfx950 -O2 -o instr_rate instr_rate.hip
+// runs a long stream of one instruction; s_memtime ticks per wave-instruction per SIMD follow from the time at
+// which the LAST wave is done (the oldest wave of a SIMD runs at single-wave speed whatever the others do).  Build: hipcc --offload-arch=gfx950 -O2 -o instr_rate instr_rate.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -75,20 +75,22 @@ template <int OP> __global__ void k(double *out, unsigned long long *cyc, double
         }
     }
     unsigned long long t1 = clock64();
-    if (threadIdx.x == 0) cyc[0] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) cyc[threadIdx.x >> 6] = t1 - t0;      // every wave: the last one to finish is what counts
     out[threadIdx.x] = a0 + a1 + a2 + a3 + f0 + f1 + f2 + f3 + u0 + u1 + u2 + u3 + (double)(q0 + q1 + q2 + q3);
 }
 
 template <int OP> void run(const char *name)
 {
     double *out; unsigned long long *cyc;
-    hipMalloc(&out, 1024 * 8); hipMalloc(&cyc, 8);
-    for (int waves : {1, 4, 8, 12, 16}) {
+    (void)hipMalloc(&out, 1024 * 8); (void)hipMalloc(&cyc, 16 * 8);
+    for (int waves : {4, 8, 12, 16}) {
         hipLaunchKernelGGL(k<OP>, dim3(1), dim3(64 * waves), 0, 0, out, cyc, 1.5);
         hipDeviceSynchronize();
-        unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
-        double per_simd = (double)c / ((double)REP * OUTER * ((waves + 3) / 4));
-        std::printf("%-16s waves=%2d  %.2f clock64 ticks per wave-instruction per SIMD\n", name, waves, per_simd);
+        unsigned long long c[16]; (void)hipMemcpy(c, cyc, 16 * 8, hipMemcpyDeviceToHost);
+        unsigned long long first = c[0], last = 0;
+        for (int w = 0; w < waves; w++) last = c[w] > last ? c[w] : last;
+        std::printf("%-20s waves=%2d  first wave %.2f ticks per instruction, all waves done %.2f ticks per wave-instruction per SIMD\n", name, waves,
+                    (double)first / ((double)REP * OUTER), (double)last / ((double)REP * OUTER * ((waves + 3) / 4)));
     }
     hipFree(out); hipFree(cyc);
 }
