@@ -110,8 +110,11 @@ __device__ __forceinline__ double fx_to_double(fx128 a)
     if (neg) a = fx_neg(a);
     unsigned long long hi = (unsigned long long)a.hi, lo = a.lo;
     double r;
-    if (hi == 0ull) {
-        r = (double)lo * 0x1p-64;
+    if (__builtin_expect(hi < (1ull << 21), 1)) {
+        // below 2^21 (every sum of a sane cost): the integer part and the upper half of the fraction fill at most 53
+        // bits, so their sum is exact, and adding the lower half rounds the exact value once, to nearest even
+        const double top = (double)(unsigned)hi + (double)(unsigned)(lo >> 32) * 0x1p-32;
+        r = top + (double)(unsigned)lo * 0x1p-64;
     } else {
         int lz = __clzll((long long)hi);
         unsigned long long top = lz ? ((hi << lz) | (lo >> (64 - lz))) : hi;
