@@ -251,6 +251,103 @@ void og_uniform_sphere(int count, float *pos)
     }
 }
 
+/* ======================================================================== */
+/* Deterministic.fs: the seeded workload generators                          */
+/* ======================================================================== */
+
+static inline float dist3(const float *p, const float *q);
+
+/* Deterministic.fs:30-35.  HashRNG.nextVector3: three draws at 3i, 3i+1, 3i+2, each mapped to
+ * [-1, 1] in fp64 and rounded to fp32. */
+static void hashrng_next_vector3(const char *seed, int index, float out[3])
+{
+    for (int k = 0; k < 3; k++)
+        out[k] = (float)(og_hashrng_next_float(seed, index * 3 + k) * 2.0 - 1.0);
+}
+
+/* Deterministic.fs:44-68.  DeterministicDistribution.fibonacciSphere: theta = phi * i * 2 * pi in
+ * that order of multiplication; the perturbation is applied in fp32 (Vector3 arithmetic). */
+void og_fibonacci_sphere(const char *seed, int count, double perturbation, float *pos)
+{
+    if (count <= 0) return;
+    if (count == 1) { pos[0] = pos[1] = pos[2] = 0.0f; return; }
+    const double phi = (1.0 + sqrt(5.0)) / 2.0;
+    for (int i = 0; i < count; i++) {
+        double y = 1.0 - ((double)i / (double)(count - 1)) * 2.0;
+        double radius = sqrt(1.0 - y * y);
+        double theta = phi * (double)i * 2.0 * M_PI;
+        float b[3] = { (float)(radius * cos(theta)), (float)y, (float)(radius * sin(theta)) };
+        if (perturbation > 0.0) {
+            float nz[3];
+            hashrng_next_vector3(seed, i, nz);
+            float s = (float)perturbation;
+            for (int k = 0; k < 3; k++) {
+                float t = nz[k] * s;
+                b[k] = b[k] + t;
+            }
+        }
+        pos[3*i] = b[0]; pos[3*i+1] = b[1]; pos[3*i+2] = b[2];
+    }
+}
+
+/* Deterministic.fs:71-87.  DeterministicDistribution.uniformSphere (points IN a ball of the radius). */
+void og_seeded_uniform_sphere(const char *seed, int count, double radius, float *pos)
+{
+    for (int i = 0; i < count; i++) {
+        double u = og_hashrng_next_float(seed, i * 3);
+        double v = og_hashrng_next_float(seed, i * 3 + 1);
+        double w = og_hashrng_next_float(seed, i * 3 + 2);
+        double theta = 2.0 * M_PI * u;
+        double ph = acos(2.0 * v - 1.0);
+        double r = pow(w, 1.0 / 3.0) * radius;
+        pos[3*i]   = (float)(r * sin(ph) * cos(theta));
+        pos[3*i+1] = (float)(r * sin(ph) * sin(theta));
+        pos[3*i+2] = (float)(r * cos(ph));
+    }
+}
+
+/* Deterministic.fs:105-116.  DeterministicGeneration.createGraph: node 0 Origin, n-1 Terminal (0 wins
+ * when n = 1), the others Standard (nextFloat seed (i + 1000)); no edges. */
+void og_create_graph(const char *seed, int n, double perturbation, float *pos, uint8_t *kind, double *value)
+{
+    og_fibonacci_sphere(seed, n, perturbation, pos);
+    for (int i = 0; i < n; i++) {
+        if (i == 0) { kind[i] = OG_ORIGIN; value[i] = 0.0; }
+        else if (i == n - 1) { kind[i] = OG_TERMINAL; value[i] = 0.0; }
+        else { kind[i] = OG_STANDARD; value[i] = og_hashrng_next_float(seed, i + 1000); }
+    }
+}
+
+/* Deterministic.fs:119-135.  DeterministicGeneration.generateEdges: pairs i < j in row order, kept when
+ * nextFloat seed (i*1000 + j) < 1 / (1 + d^2) until int(n * avgDegree / 2) edges exist (the reference
+ * goes on hashing the remaining pairs without effect; this stops).  Every new edge is consed onto the
+ * list, so the output (LIST order, index 0 = head) is the reverse of the order of discovery.
+ * Returns the number of edges; `weights` (the fp32 distance widened) may be NULL. */
+int og_generate_edges(const char *seed, const float *pos, int n, double avg_degree, int32_t *edges, double *weights, int cap)
+{
+    int target = (int)((double)n * avg_degree / 2.0);
+    int cnt = 0;
+    for (int i = 0; i < n && cnt < target; i++)
+        for (int j = i + 1; j < n && cnt < target; j++) {
+            float d = dist3(pos + 3*i, pos + 3*j);
+            double probability = 1.0 / (1.0 + (double)d * (double)d);
+            double threshold = og_hashrng_next_float(seed, (int)((uint32_t)i * 1000u + (uint32_t)j));
+            if (threshold < probability) {
+                if (cnt >= cap) return -1;
+                edges[2*cnt] = i; edges[2*cnt+1] = j;
+                if (weights) weights[cnt] = (double)d;
+                cnt++;
+            }
+        }
+    for (int a = 0, b = cnt - 1; a < b; a++, b--) {
+        int32_t t0 = edges[2*a], t1 = edges[2*a+1];
+        edges[2*a] = edges[2*b]; edges[2*a+1] = edges[2*b+1];
+        edges[2*b] = t0; edges[2*b+1] = t1;
+        if (weights) { double w = weights[a]; weights[a] = weights[b]; weights[b] = w; }
+    }
+    return cnt;
+}
+
 void og_default_config(og_config *c)
 {
     /* ProceduralGeneration.fs:100-107 */

@@ -130,6 +130,11 @@ int og_swap_frequency(int node_count);
 double og_accept_probability(double current, double proposed, double temperature);
 double og_swap_probability(double c1, double t1, double c2, double t2);
 void og_uniform_sphere(int count, float *pos);
+/* Deterministic.fs:44-135: the seeded workload generators */
+void og_fibonacci_sphere(const char *seed, int count, double perturbation, float *pos);
+void og_seeded_uniform_sphere(const char *seed, int count, double radius, float *pos);
+void og_create_graph(const char *seed, int n, double perturbation, float *pos, uint8_t *kind, double *value);
+int og_generate_edges(const char *seed, const float *pos, int n, double avg_degree, int32_t *edges, double *weights, int cap);
 
 /* ---- stepping ----------------------------------------------------------- */
 

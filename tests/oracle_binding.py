@@ -100,6 +100,13 @@ def lib():
         L.og_swap_frequency.argtypes = [C.c_int]
         L.og_geometric_ladder.argtypes = [C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.og_uniform_sphere.argtypes = [C.c_int, C.POINTER(C.c_float)]
+        L.og_fibonacci_sphere.argtypes = [C.c_char_p, C.c_int, C.c_double, C.POINTER(C.c_float)]
+        L.og_seeded_uniform_sphere.argtypes = [C.c_char_p, C.c_int, C.c_double, C.POINTER(C.c_float)]
+        L.og_create_graph.argtypes = [C.c_char_p, C.c_int, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_uint8),
+                                      C.POINTER(C.c_double)]
+        L.og_generate_edges.restype = C.c_int
+        L.og_generate_edges.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_int, C.c_double, C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_double), C.c_int]
         L.og_default_config.argtypes = [C.POINTER(Config)]
         L.og_run.restype = C.c_int
         L.og_run.argtypes = [C.POINTER(RunArgs), C.POINTER(Config)]
@@ -134,6 +141,39 @@ def uniform_sphere(n):
     pos = np.zeros((n, 3), np.float32)
     lib().og_uniform_sphere(n, _p(pos, C.c_float))
     return pos
+
+
+def fibonacci_sphere(seed, n, perturbation):
+    pos = np.zeros((max(n, 0), 3), np.float32)
+    lib().og_fibonacci_sphere(seed.encode(), n, perturbation, _p(pos, C.c_float))
+    return pos
+
+
+def seeded_uniform_sphere(seed, n, radius):
+    pos = np.zeros((max(n, 0), 3), np.float32)
+    lib().og_seeded_uniform_sphere(seed.encode(), n, radius, _p(pos, C.c_float))
+    return pos
+
+
+def create_graph(seed, n, perturbation):
+    """DeterministicGeneration.createGraph (Deterministic.fs:105-116): pos, kind, value."""
+    pos = np.zeros((n, 3), np.float32)
+    kind = np.zeros(n, np.uint8)
+    value = np.zeros(n, np.float64)
+    lib().og_create_graph(seed.encode(), n, perturbation, _p(pos, C.c_float), _p(kind, C.c_uint8), _p(value, C.c_double))
+    return pos, kind, value
+
+
+def generate_edges(seed, pos, avg_degree):
+    """DeterministicGeneration.generateEdges (Deterministic.fs:119-135): edges in list order, weights."""
+    n = len(pos)
+    cap = max(int(n * avg_degree / 2.0), 1)
+    edges = np.zeros((cap, 2), np.int32)
+    w = np.zeros(cap, np.float64)
+    pos = np.ascontiguousarray(pos, np.float32)
+    cnt = lib().og_generate_edges(seed.encode(), _p(pos, C.c_float), n, avg_degree, _p(edges, C.c_int32), _p(w, C.c_double), cap)
+    assert cnt >= 0
+    return edges[:cnt].copy(), w[:cnt].copy()
 
 
 def default_kinds(n):

@@ -143,6 +143,20 @@ def test_trace_parity_philox(gpu_lib, n, T, G, iters, f, layout, flags):
     pu.assert_same_run(wl, gpu, orc, iters)
 
 
+@pytest.mark.parametrize("flags", PLACEMENTS)
+@pytest.mark.parametrize("n,T,iters", [(60, 5, 400), (700, 6, 300)])
+def test_trace_parity_seeded_generator_start(gpu_lib, n, T, iters, flags):
+    """The starting graph of DeterministicGeneration.generate (reference src/Deterministic.fs:138-140,166):
+    perturbed fibonacci sphere, hash-selected edges (nearly all of them leave the first few nodes),
+    every replica starting from the same graph."""
+    from procgen_amd import deterministic as det
+    wl = det.deterministic_workload(f"seeded-{n}", n, T)
+    f = nt.swap_frequency(n)
+    gpu = pu.gpu_run(wl, iters, f, seed=f"seeded-{n}", flags=flags)
+    orc = pu.oracle_run(wl, iters, f, seed=f"seeded-{n}")
+    pu.assert_same_run(wl, gpu, orc, iters)
+
+
 @pytest.mark.parametrize("cluster", CLUSTERS)
 @pytest.mark.parametrize("n,T,G,iters,f", [(20, 5, 1, 300, 8), (300, 6, 2, 200, 34), (1000, 4, 2, 130, 63)])
 def test_trace_parity_clustered(gpu_lib, n, T, G, iters, f, cluster):
