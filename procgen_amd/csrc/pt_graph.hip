@@ -52,7 +52,7 @@ struct pt_graph_engine {
     DevBuf px, py, pz, ea, eb, et, ebuf, ecount, kind, value, origin, terminal, rowend, adj, adj4, cost, temps,
         slot_of_rep, rep_of_slot, cells, sorted, queue, bitmap, collbuf, comm, chain_u, swap_u, trace, swap_trace,
         stats, swap_stats, status, terms, group_keys, legacy_in, legacy_out, legacy_flag, dacc, dreach, dvis, dparent, dparscr, dlabel, dlabscr, epk,
-        dparent32, dparscr32, bvis, bjmp, bdist, bcomm,
+        dparent32, dparscr32, bvis, bjmp, bdist, bcomm, binc, bdeg,
         conv_hist, conv_swaps, conv_swap_total, conv_out;
     // the drop-in iteration: what the caller's position array holds if nobody touched it since the last call
     std::vector<unsigned char> legacy_shadow;
@@ -584,7 +584,11 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         A(e->bvis, sizeof(unsigned) * (size_t)R * 3 * nwords);
         A(e->bjmp, sizeof(unsigned) * (size_t)R * N);
         A(e->bdist, sizeof(float) * (size_t)R * N);
-        if (e->CB > 1) A(e->bcomm, sizeof(BigComm) * (size_t)R);
+        if (e->CB > 1) {
+            A(e->bcomm, sizeof(BigComm) * (size_t)R);
+            A(e->binc, sizeof(unsigned) * (size_t)R * N * BIGC_INC);
+            A(e->bdeg, sizeof(int) * (size_t)R * N);
+        }
     }
     if (herr == hipSuccess && e->delta_mode && e->delta_lds_bytes > 64 * 1024)
         herr = hipFuncSetAttribute(e->ept == 48 ? (const void *)pt_graph_delta_kernel<48, 32, 512>
@@ -659,6 +663,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         P.dparent32 = e->dparent32.as<unsigned>(); P.dparscr32 = e->dparscr32.as<unsigned>();
         P.bvis = e->bvis.as<unsigned>(); P.bjmp = e->bjmp.as<unsigned>(); P.bdist = e->bdist.as<float>();
         P.CB = e->CB; P.R = e->R; P.bcomm = e->bcomm.as<BigComm>();
+        if (e->CB > 1) { P.binc = e->binc.as<unsigned>(); P.bdeg = e->bdeg.as<int>(); }
     }
 
     SwapParams &S = e->SP;

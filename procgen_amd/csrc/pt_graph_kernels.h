@@ -93,6 +93,8 @@ struct GraphParams {
     float *bdist;               // [R][N]  distances to the proposed centroid between the two distribution passes
     int CB, R;                  // pt_graph_bigc_kernel: workgroups per replica; replicas of this engine
     struct BigComm *bcomm;      // [R] cluster records of that kernel
+    unsigned *binc;             // [R][N][16]  that kernel's per-node lists of incident edges: (other end << 1) | (1 when the edge leaves the node)
+    int *bdeg;                  // [R][N]  entries in use; above 16: the node's list overflowed and is not used
     // convergence monitoring (null when off): cost of every chain after every step, a ring per chain
     double *conv_hist;          // [G][Tl][conv_window], step s at index s % conv_window
     int conv_window;
