@@ -308,6 +308,32 @@ def test_trace_parity_streaming_cluster(gpu_lib, case, members):
     assert np.array_equal(gpu["terms"][0, :, 6], gpu["cost"][0])
 
 
+@pytest.mark.parametrize("members", [2, 16])
+@pytest.mark.parametrize("self_loops", [False, True])
+def test_streaming_cluster_incidence_lists_at_the_brim(gpu_lib, members, self_loops):
+    """The clustered streaming kernel keeps per-node lists of incident edges with room for 16.  Here most nodes
+    have about that many, on a hot ladder that mostly adds and removes edges, over several launches: lists fill up
+    and overflow under accepted additions, overflowed nodes take the pass over the edge list, the next launch
+    rebuilds them; uploaded self loops (which the lists leave out) can be drawn for removal."""
+    n, T, iters, f = 40, 4, 900, 9
+    wl = wlm.graph_workload("brim", n, T, 1, avg_degree=15.0, edge_headroom=2.0)
+    if self_loops:
+        ec = int(wl["ecount"][0, 0])
+        extra = np.array([[3, 3], [17, 17], [3, 3], [0, 0], [39, 39]], np.int32)
+        wl["edges"][0, :, ec:ec + len(extra)] = extra
+        wl["ecount"][:] = ec + len(extra)
+    wl["temperatures"][:] = [[9.0, 6.0, 3.5, 2.2]]
+    deg = np.bincount(wl["edges"][0, 0, :wl["ecount"][0, 0]].ravel(), minlength=n)
+    assert (deg <= 16).sum() >= 5 and (deg > 16).sum() >= 5
+    gpu = pu.gpu_run(wl, iters, f, seed="brim", chunks=[100, 350, 450], flags=nt.FLAG_STREAMING_INCREMENTAL, cluster_size=members)
+    orc = pu.oracle_run(wl, iters, f, seed="brim")
+    pu.assert_same_run(wl, gpu, orc, iters)
+    tr = gpu["trace"]
+    assert ((tr["kind"] == 1) & ((tr["flags"] & 5) == 4)).sum() > 50, "additions were meant to be accepted"
+    assert ((tr["kind"] == 2) & ((tr["flags"] & 5) == 4)).sum() > 50, "removals were meant to be accepted"
+    assert np.array_equal(gpu["terms"][0, :, 6], gpu["cost"][0])
+
+
 def test_streaming_cluster_matches_one_workgroup_at_150k_nodes(gpu_lib):
     """Large enough for every member to stream thousands of nodes: the trace of the clustered kernel
     equals the single-workgroup kernel's (which the oracle pins at 70 000 nodes)."""
