@@ -46,6 +46,7 @@ struct pt_graph_engine {
     int ept = 24;               // edges each thread of that kernel holds in registers (24: any workgroup size, 48: at most 512 threads)
     int C = 1;                  // workgroups per replica
     size_t lds_bytes = 0, delta_lds_bytes = 0;
+    size_t bigc_lds_bytes = 0;  // pt_graph_bigc_kernel: its header plus the room for distances between the two distribution passes
     hipStream_t stream = nullptr;
     GraphParams P;
     SwapParams SP;
@@ -171,7 +172,7 @@ int launch_steps(pt_graph_engine *e, long long step0, int nsteps)
     if (e->big_mode && e->CB > 1) {
         PT_HIP_TRY(hipMemsetAsync(e->bcomm.p, 0, e->bcomm.bytes, e->stream));
         const unsigned blocks = (unsigned)((e->R + 7) / 8 * 8 * e->CB);
-        hipLaunchKernelGGL(pt_graph_bigc_kernel, dim3(blocks), dim3(e->block), e->lds_bytes, e->stream, e->P, step0, nsteps);
+        hipLaunchKernelGGL(pt_graph_bigc_kernel, dim3(blocks), dim3(e->block), e->bigc_lds_bytes, e->stream, e->P, step0, nsteps);
     } else if (e->big_mode)
         hipLaunchKernelGGL(pt_graph_big_kernel, dim3(e->R), dim3(e->block), e->lds_bytes, e->stream, e->P, step0, nsteps);
     else if (e->delta_mode && e->ept == 48)
@@ -487,10 +488,12 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         unsigned init[2] = {0u, 1u}, res[2] = {0u, 0u};
         if (probe.alloc(sizeof init) != hipSuccess) { (void)hipGetLastError(); return false; }
         bool ok = hipMemcpyAsync(probe.p, init, sizeof init, hipMemcpyHostToDevice, e->stream) == hipSuccess;
-        if (ok && lds > 64 * 1024)
-            ok = hipFuncSetAttribute((const void *)pt_census_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        // (the clustered streaming kernel takes a CU's whole LDS)
+        const size_t foot = e->big_mode ? std::max(lds, LDS_BUDGET) : lds;
+        if (ok && foot > 64 * 1024)
+            ok = hipFuncSetAttribute((const void *)pt_census_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)foot) == hipSuccess;
         if (ok) {
-            hipLaunchKernelGGL(pt_census_kernel, dim3(blocks), dim3(64), lds, e->stream, probe.as<unsigned>(), probe.as<unsigned>() + 1, blocks);
+            hipLaunchKernelGGL(pt_census_kernel, dim3(blocks), dim3(64), foot, e->stream, probe.as<unsigned>(), probe.as<unsigned>() + 1, blocks);
             ok = hipGetLastError() == hipSuccess &&
                  hipMemcpyAsync(res, probe.p, sizeof res, hipMemcpyDeviceToHost, e->stream) == hipSuccess &&
                  hipStreamSynchronize(e->stream) == hipSuccess;
@@ -605,8 +608,10 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     }
     if (herr == hipSuccess && e->big_mode && lds > 64 * 1024) {
         herr = hipFuncSetAttribute((const void *)pt_graph_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (herr == hipSuccess)
-            herr = hipFuncSetAttribute((const void *)pt_graph_bigc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    if (herr == hipSuccess && e->big_mode && e->CB > 1) {
+        e->bigc_lds_bytes = LDS_BUDGET;
+        herr = hipFuncSetAttribute((const void *)pt_graph_bigc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->bigc_lds_bytes);
     }
     if (herr != hipSuccess) {
         int code = herr == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP;
@@ -663,7 +668,12 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         P.dparent32 = e->dparent32.as<unsigned>(); P.dparscr32 = e->dparscr32.as<unsigned>();
         P.bvis = e->bvis.as<unsigned>(); P.bjmp = e->bjmp.as<unsigned>(); P.bdist = e->bdist.as<float>();
         P.CB = e->CB; P.R = e->R; P.bcomm = e->bcomm.as<BigComm>();
-        if (e->CB > 1) { P.binc = e->binc.as<unsigned>(); P.bdeg = e->bdeg.as<int>(); }
+        if (e->CB > 1) {
+            P.binc = e->binc.as<unsigned>(); P.bdeg = e->bdeg.as<int>();
+            long long runs = (long long)((e->bigc_lds_bytes - ((sizeof(Shared) + 15) & ~(size_t)15)) / 16);
+            if (const char *v = std::getenv("PROCGEN_PT_BIGC_CACHE_RUNS")) runs = std::min(runs, std::max(0ll, std::atoll(v)));     // test hook
+            P.bigc_cache_runs = (int)runs;
+        }
     }
 
     SwapParams &S = e->SP;

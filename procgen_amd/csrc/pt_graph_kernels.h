@@ -92,6 +92,7 @@ struct GraphParams {
     unsigned *bjmp;             // [R][N]  scratch of the subtree search
     float *bdist;               // [R][N]  distances to the proposed centroid between the two distribution passes
     int CB, R;                  // pt_graph_bigc_kernel: workgroups per replica; replicas of this engine
+    int bigc_cache_runs;        // that kernel: runs of four distances a workgroup keeps in LDS between the two distribution passes
     struct BigComm *bcomm;      // [R] cluster records of that kernel
     unsigned *binc;             // [R][N][16]  that kernel's per-node lists of incident edges: (other end << 1) | (1 when the edge leaves the node)
     int *bdeg;                  // [R][N]  entries in use; above 16: the node's list overflowed and is not used

@@ -334,6 +334,19 @@ def test_streaming_cluster_incidence_lists_at_the_brim(gpu_lib, members, self_lo
     assert np.array_equal(gpu["terms"][0, :, 6], gpu["cost"][0])
 
 
+@pytest.mark.parametrize("runs", [0, 37])
+def test_streaming_cluster_distance_cache_split(gpu_lib, runs, monkeypatch):
+    """The clustered streaming kernel keeps the distances of the first distribution pass in LDS as far as they fit and
+    sends the rest through global memory; at test sizes everything fits, so the room is cut down here (to nothing,
+    and to 37 runs of four, which splits the first wave's nodes between the two routes)."""
+    monkeypatch.setenv("PROCGEN_PT_BIGC_CACHE_RUNS", str(runs))
+    wl = _topology_case("clump")
+    iters, f = 300, 7
+    gpu = pu.gpu_run(wl, iters, f, seed="clump", flags=nt.FLAG_STREAMING_INCREMENTAL, cluster_size=2)
+    orc = pu.oracle_run(wl, iters, f, seed="clump")
+    pu.assert_same_run(wl, gpu, orc, iters)
+
+
 def test_streaming_cluster_matches_one_workgroup_at_150k_nodes(gpu_lib):
     """Large enough for every member to stream thousands of nodes: the trace of the clustered kernel
     equals the single-workgroup kernel's (which the oracle pins at 70 000 nodes)."""
