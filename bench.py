@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full-evaluation", action="store_true", help="re-evaluate the full cost per proposal")
     ap.add_argument("--cluster", type=int, default=0, help="workgroups per replica (0 = choose)")
+    ap.add_argument("--block-threads", type=int, default=0, help="threads per workgroup (0 = choose)")
     ap.add_argument("--split-ladder", action="store_true",
                     help="one ladder of replicas x N temperatures split over the N ranks, energies all-gathered per swap interval")
     ap.add_argument("--workload", default="graphs", choices=["graphs", "chunks"],
@@ -320,7 +321,8 @@ def main():
             wl[k] = np.ascontiguousarray(whole[k][:, rank * R:(rank + 1) * R])
         wl["temps"] = R
         eng = GraphEngine(n, wl["ecap"], R, 1, seed="procgen-bench/c5", device=dev, ladder_temp_count=Tl,
-                          ladder_slot_base=rank * R, flags=flags, cluster_size=ARGS.cluster)
+                          ladder_slot_base=rank * R, flags=flags, cluster_size=ARGS.cluster,
+                          block_threads=ARGS.block_threads)
         driver = SplitLadder(GraphEngineShard(eng), device=torch.device("cpu") if REHEARSAL else None)
     else:
         distinct = min(G, 16)                        # distinct ladders generated; tiled when more are asked for
@@ -331,7 +333,7 @@ def main():
                 wl[k] = np.ascontiguousarray(np.tile(wl[k], (reps,) + (1,) * (wl[k].ndim - 1))[:G])
             wl["groups"] = G
         eng = GraphEngine(n, wl["ecap"], R, G, seed="procgen-bench/c2", device=dev, group_base=rank * G,
-                          flags=flags, cluster_size=ARGS.cluster)
+                          flags=flags, cluster_size=ARGS.cluster, block_threads=ARGS.block_threads)
         driver = None
     info = eng.info()
     f = eng.swap_frequency

@@ -172,7 +172,10 @@ int launch_steps(pt_graph_engine *e, long long step0, int nsteps)
     if (e->big_mode && e->CB > 1) {
         PT_HIP_TRY(hipMemsetAsync(e->bcomm.p, 0, e->bcomm.bytes, e->stream));
         const unsigned blocks = (unsigned)((e->R + 7) / 8 * 8 * e->CB);
-        hipLaunchKernelGGL(pt_graph_bigc_kernel, dim3(blocks), dim3(e->block), e->bigc_lds_bytes, e->stream, e->P, step0, nsteps);
+        if (e->block <= 512)
+            hipLaunchKernelGGL(pt_graph_bigc_kernel<512>, dim3(blocks), dim3(e->block), e->bigc_lds_bytes, e->stream, e->P, step0, nsteps);
+        else
+            hipLaunchKernelGGL(pt_graph_bigc_kernel<1024>, dim3(blocks), dim3(e->block), e->bigc_lds_bytes, e->stream, e->P, step0, nsteps);
     } else if (e->big_mode)
         hipLaunchKernelGGL(pt_graph_big_kernel, dim3(e->R), dim3(e->block), e->lds_bytes, e->stream, e->P, step0, nsteps);
     else if (e->delta_mode && e->ept == 48)
@@ -611,7 +614,8 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     }
     if (herr == hipSuccess && e->big_mode && e->CB > 1) {
         e->bigc_lds_bytes = LDS_BUDGET;
-        herr = hipFuncSetAttribute((const void *)pt_graph_bigc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->bigc_lds_bytes);
+        herr = hipFuncSetAttribute(e->block <= 512 ? (const void *)pt_graph_bigc_kernel<512> : (const void *)pt_graph_bigc_kernel<1024>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->bigc_lds_bytes);
     }
     if (herr != hipSuccess) {
         int code = herr == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP;
