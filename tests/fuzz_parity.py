@@ -1,6 +1,6 @@
 """Randomised parity sweeps of the HIP engines against the CPU oracle (GPU needed).
 
-Not collected by pytest: run it by hand, `python tests/fuzz_parity.py [cases] [seed] [graph|chunk|collide|large|traceoff]`.
+Not collected by pytest: run it by hand, `python tests/fuzz_parity.py [cases] [seed] [graph|chunk|collide|large|traceoff|cluster]`.
   graph    every case draws a graph shape, a layout scale, node roles, a temperature ladder, a move set, cost
            weights, the draws (Philox, or injected and salted with extreme values), a swap interval, a launch
            split and one of the engine's kernel routes;
@@ -8,6 +8,9 @@ Not collected by pytest: run it by hand, `python tests/fuzz_parity.py [cases] [s
   chunk    the voxel-chunk engine: air share, opened boxes, uniform chunks, fractional densities, ladders, weights;
   traceoff sparse graphs on hot ladders with NO step trace recorded (the production paths of the incremental
            kernels, early rejection of tree-edge removals included): final state, swaps, slot map, counts;
+  cluster  the graph cases through the clustered streaming kernel only (2 to 16 workgroups per replica), with node
+           degrees on both sides of what its per-node lists of incident edges hold, uploaded self loops, hot ladders,
+           half of the cases without a step trace;
   collide  collision_detection, both entries: clumps, coincident points, points planted at the bounds, far offsets.
 Each case runs on the GPU through the C ABI and on the oracle, and the results (for the engines: the whole
 trace) are compared bit for bit.  A failing case prints the numbers needed to repeat it.
@@ -128,6 +131,44 @@ def make_case(rng, index):
                 summary=f"n={n} T={T} G={G} iters={iters} f={f} deg={deg} E={wl['ecount'][:, 0].tolist()} "
                         f"mut={mutation_mode} w={'custom' if weights else 'default'} temps={tm} chunks={chunks} "
                         f"route={route[0]} draws={'injected' if draws else 'philox'}")
+
+
+CLUSTER = False                # the clustered streaming kernel only
+CLUSTER_ROUTES = [(f"incremental-global-c{c}", dict(flags=nt.FLAG_STREAMING_INCREMENTAL, cluster_size=c)) for c in (2, 3, 5, 7, 16)]
+
+
+_make_graph_case = make_case
+
+
+def make_cluster_case(rng, index):
+    case = _make_graph_case(rng, index)
+    wl = case["wl"]
+    n, G, T = wl["n"], wl["groups"], wl["temps"]
+    iters = case["iters"]
+    if n >= 8 and rng.random() < 0.6:
+        # a denser list: mean degree 10 to 24, so that nodes sit on both sides of 16 incident edges
+        deg = float(rng.choice([10.0, 15.0, 17.0, 24.0]))
+        n_edges = min(max(int(n * deg / 2.0), n - 1), n * (n - 1) // 2)
+        dense = wlm.graph_workload("fuzz-dense", n, T, G, avg_degree=deg, edge_headroom=1.0 + (iters + 16) / max(n_edges, 1), index=index)
+        dense["pos"], dense["kind"], dense["value"], dense["temperatures"] = wl["pos"], wl["kind"], wl["value"], wl["temperatures"]
+        wl = dense
+    if rng.random() < 0.3:                         # self loops in the uploaded list
+        for g in range(G):
+            ec = int(wl["ecount"][g, 0])
+            k = int(min(rng.integers(1, 6), wl["ecap"] - iters - 1 - ec))
+            if k > 0:
+                v = rng.integers(0, n, size=k).astype(np.int32)
+                wl["edges"][g, :, ec:ec + k] = np.stack([v, v], axis=1)
+                wl["ecount"][g, :] = ec + k
+    if rng.random() < 0.5 and T > 1:               # hot: four proposals out of five add or remove an edge
+        wl["temperatures"][:] = nt.geometric_ladder(float(rng.choice([0.6, 2.5])), float(rng.choice([6.0, 12.0])), T)
+    case["wl"] = wl
+    # (a clustered grid must be co-resident: replicas rounded up to eight, times the members, within the 256 CUs)
+    fits = [rt for rt in CLUSTER_ROUTES if (G * T + 7) // 8 * 8 * rt[1]["cluster_size"] <= 256]
+    case["route"] = fits[int(rng.integers(0, len(fits)))]
+    case["trace"] = bool(rng.random() < 0.5)
+    case["summary"] += f" -> cluster route={case['route'][0]} E={wl['ecount'][:, 0].tolist()} trace={case['trace']}"
+    return case
 
 
 def run_case(case, seed):
@@ -261,6 +302,8 @@ def main():
         LARGE = True
     if len(sys.argv) > 3 and sys.argv[3] == "collide":
         make_case, run_case = make_collide_case, run_collide_case
+    if len(sys.argv) > 3 and sys.argv[3] == "cluster":
+        make_case = make_cluster_case
     early = [0]
     if len(sys.argv) > 3 and sys.argv[3] == "traceoff":
         graph_case = run_case
