@@ -427,13 +427,13 @@ def main():
                                                     "not bytes moved: the state is in LDS)"})
         else:
             # replica state streamed from HBM
-            moved = (n * 20 + 8 * e_mean)               # one perturbation: positions twice + distances, edge endpoints
+            moved = n * 20                              # one perturbation: positions read, distances written and read back
             bpp = traffic_pp if traffic_pp is not None else moved
             achieved = bpp * props_per_launch / launch_s / 1e9
             roofline = dict(common, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                             bytes_per_proposal=bpp,
                             bytes_note="HBM bytes per proposal: the committed PMC measurement of this kernel and shape when one is "
-                                       "on file, else what one incremental perturbation streams (8E + 12N + 8N)",
+                                       "on file, else what one incremental perturbation streams at most (12N + 8N)",
                             reference_work={"bytes_per_proposal": ref_bytes, "rate_GBs": hbm_equiv,
                                             "lane_ops_rate_TFLOPs": valu})
         shape = ("configs[1]" if headline else "configs[4] shape" if split else "other shape")

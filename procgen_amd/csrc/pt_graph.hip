@@ -62,6 +62,7 @@ struct pt_graph_engine {
     long long conv_first_step = 0;  // first step the history holds
     long long step = 0;
     long long steps_since_init = 0, relabel_every = 0;     // incremental kernels: see launch_steps
+    bool relabel_forced = false;                            // test hook: rebuild at every interval, whatever the labels reached
     long long trace_steps = 0, trace_passes = 0;
     bool uploaded = false;
     std::mutex mu;
@@ -141,11 +142,28 @@ int launch_steps(pt_graph_engine *e, long long step0, int nsteps)
     // rebuilt from scratch by the init kernel: same cost, same sums, same reached sets bit for bit, a
     // fresh search tree with labels below N.  No launch runs more than relabel_every steps on one set
     // of labels: a longer request is cut into pieces with a rebuild between them.
+    // relabel_every is the worst case (every step re-reaching through every edge).  Real steps use a
+    // handful of labels, and a rebuild is a full evaluation by one workgroup per replica (tens of
+    // milliseconds at a million nodes), so when the worst-case budget is spent the host first reads how
+    // far the counters really got and, if at least a quarter of the budget is still there, goes on.
     if (e->delta_mode || e->big_mode) {
         if (e->steps_since_init >= e->relabel_every) {
-            int rc = launch_init(e, e->P, 1);
-            if (rc) return rc;
-            e->steps_since_init = 0;
+            long long room = 0;
+            if (!e->relabel_forced) {
+                std::vector<int> reach((size_t)e->R * 4);
+                PT_HIP_TRY(hipStreamSynchronize(e->stream));
+                PT_HIP_TRY(hipMemcpy(reach.data(), e->dreach.p, reach.size() * sizeof(int), hipMemcpyDeviceToHost));
+                unsigned top = 0;                               // the largest label in use by any replica
+                for (int r = 0; r < e->R; r++) top = std::max(top, (unsigned)reach[(size_t)r * 4 + 2]);
+                room = (long long)((0xfffffffeull - (unsigned long long)top) / ((unsigned long long)e->Ecap + 2ull));
+                room = std::min(room, e->relabel_every);
+            }
+            if (room > 0 && room * 4 >= e->relabel_every) e->steps_since_init = e->relabel_every - room;
+            else {
+                int rc = launch_init(e, e->P, 1);
+                if (rc) return rc;
+                e->steps_since_init = 0;
+            }
         }
         const long long room = e->relabel_every - e->steps_since_init;
         if (nsteps > room) {
@@ -465,6 +483,10 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         // finds its head unvisited) plus one; labels restart below N
         e->relabel_every = std::max<long long>(1, (3ll << 30) / ((long long)e->Ecap + 2));
         if (const char *v = std::getenv("PROCGEN_PT_RELABEL_EVERY")) {                   // test hook
+            const long long k = std::atoll(v);
+            if (k > 0) { e->relabel_every = k; e->relabel_forced = true; }
+        }
+        if (const char *v = std::getenv("PROCGEN_PT_RELABEL_BUDGET")) {                  // test hook: a small worst-case budget, not forced
             const long long k = std::atoll(v);
             if (k > 0) e->relabel_every = k;
         }

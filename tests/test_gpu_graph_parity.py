@@ -287,6 +287,20 @@ def test_rebuild_inside_a_swap_interval(gpu_lib, flags, monkeypatch):
     assert len(np.unique(gpu["trace"]["reach0"])) > 3
 
 
+@pytest.mark.parametrize("route", [dict(flags=0), dict(flags=nt.FLAG_STREAMING_INCREMENTAL), dict(flags=nt.FLAG_STREAMING_INCREMENTAL, cluster_size=3)],
+                         ids=["incremental", "incremental-global", "incremental-global-c3"])
+def test_spent_label_budget_is_renewed_from_the_counters(gpu_lib, route, monkeypatch):
+    """When the worst-case budget of discovery labels is spent the host reads how far the counters really got and goes
+    on without a rebuild while most of the range is left (here the budget is 13 steps, so that happens dozens of times)."""
+    monkeypatch.setenv("PROCGEN_PT_RELABEL_BUDGET", "13")
+    wl = _topology_case("near-tree")
+    iters, f = 400, 50
+    gpu = pu.gpu_run(wl, iters, f, seed="renewed", chunks=[120, 280], **route)
+    orc = pu.oracle_run(wl, iters, f, seed="renewed")
+    pu.assert_same_run(wl, gpu, orc, iters)
+    assert len(np.unique(gpu["trace"]["reach0"])) > 3
+
+
 def test_trace_parity_many_small_replicas(gpu_lib):
     """More replicas than twice the CUs: the engine then picks its smallest workgroup."""
     n, T, G, iters, f = 300, 16, 40, 60, 7
