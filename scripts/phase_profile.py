@@ -60,6 +60,10 @@ def main():
         st = st_all[ids]
         tot = st.sum(axis=1)
         print(f"[{role}] cycles/proposal: mean {tot.mean() / iters:.0f} max {tot.max() / iters:.0f}")
+        if CS == 1:
+            slots = eng.replica_slots().reshape(-1)             # temperature slot of every replica (slot 0 = hottest)
+            order = np.argsort(slots[:len(tot)])
+            print("  cycles/proposal by temperature slot, hottest first:", np.round(tot[order] / iters).astype(int).tolist())
         for k, name in enumerate(NAMES_INC if inc else NAMES):
             if st[:, k].sum() > 0:
                 if name.startswith("("):
