@@ -10,9 +10,7 @@ ParallelTempering.run's loop on every replica (propose + weighted cost + Metropo
 the sequential swap pass.  The engine's default evaluation is incremental: the exact fixed-point cost
 sums are updated by the terms the move changes, which yields bit for bit the cost a full re-evaluation
 yields (--full-evaluation times the full re-evaluation kernels).  Without --steps the timed region is
-sized to last about 0.6 s.  Before the W warm-up steps comes an untimed settle phase of about 1.5 s of the
-same steps (reported as settle_steps): the chip needs about a second under load to reach the clock it then
-holds, and 20 steps timed right after 5 warm-up steps read 5 % below any later 20.
+sized to last about 0.6 s.
 
 Multi-GPU (one process per GPU, launched by torch.distributed.run):
   default          every rank runs its own ladder: independent chains shard across GPUs with no
@@ -36,7 +34,6 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X FP32 vector spec peak
 TIMED_SECONDS = 0.6            # length of the timed region when --steps is not given
-SETTLE_SECONDS = 1.5           # untimed load before the warm-up steps: the clock has settled by then
 
 
 def parse():
@@ -198,23 +195,16 @@ class Timed:
         return x
 
     def run(self, before_timed):
-        # The chip takes about a second of load to reach the clock it then holds (20 steps timed after 5 warm-up steps
-        # read 5 % below the rate of any later 20): an untimed settle phase of SETTLE_SECONDS comes first, sized from one
-        # timed step so that every rank runs the same number of steps (the split ladder's steps hold a collective).
-        self.step_fn()                              # (the first step carries one-off costs)
-        self.barrier()
-        t0 = time.perf_counter()
-        self.step_fn()
-        self.sync_fn()
-        one = self.max_over_ranks(time.perf_counter() - t0)
-        self.settle_steps = int(min(20000, max(1, math.ceil(SETTLE_SECONDS / max(one, 1e-6)))))
-        for _ in range(self.settle_steps):
-            self.step_fn()
         for _ in range(ARGS.warmup):
             self.step_fn()
         self.sync_fn()
         steps = ARGS.steps
-        if steps <= 0:                              # size the timed region
+        if steps <= 0:                              # size the timed region: one more step, timed
+            self.barrier()
+            t0 = time.perf_counter()
+            self.step_fn()
+            self.sync_fn()
+            one = self.max_over_ranks(time.perf_counter() - t0)
             steps = int(min(5000, max(2, math.ceil(TIMED_SECONDS / max(one, 1e-6)))))
         before_timed()
         self.barrier()
@@ -256,8 +246,7 @@ def main_chunks():
         eng.kernel_time(reset=True)
         st0.update(eng.stats())
 
-    timer = Timed(torch, dist, world, lambda: eng.run(f), eng.sync)
-    steps, elapsed = timer.run(before_timed)
+    steps, elapsed = Timed(torch, dist, world, lambda: eng.run(f), eng.sync).run(before_timed)
     kms, klaunch = eng.kernel_time()
     st1 = eng.stats()
     props = st1["proposals"] - st0["proposals"]
@@ -275,7 +264,7 @@ def main_chunks():
         achieved = bpp * per_launch / launch_s / 1e9
         line = {
             "metric": "Metropolis proposals/sec (whole node), 32^3 voxel chunks x 6 temperatures", "value": props * world / elapsed,
-            "unit": "proposals/s", "n_gpus": world, "steps": steps, "warmup": ARGS.warmup, "settle_steps": timer.settle_steps,
+            "unit": "proposals/s", "n_gpus": world, "steps": steps, "warmup": ARGS.warmup,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 voxel fields, f64 cost, i128 fixed-point sums", "data": "synthetic",
             "config": {"workload": f"configs[2]: {G} voxel chunks (32^3) x {T} temperatures per GPU, terrain constraints, "
@@ -358,8 +347,7 @@ def main():
         st0.update(eng.stats())
         g0[0] = driver.gathers if split else 0
 
-    timer = Timed(torch, dist, world, step_fn, eng.sync)
-    steps, elapsed = timer.run(before_timed)
+    steps, elapsed = Timed(torch, dist, world, step_fn, eng.sync).run(before_timed)
 
     kms, klaunch = eng.kernel_time()
     st1 = eng.stats()
@@ -453,7 +441,7 @@ def main():
             "metric": "Metropolis proposals/sec (whole node), 10k-node graph x 64 replicas" if headline
                       else f"Metropolis proposals/sec (whole node), {n}-node graph x {R * G * (world if split else 1)} replicas"
                            f"{' (one ladder split over the GPUs)' if split else ''}",
-            "value": value, "unit": "proposals/s", "n_gpus": world, "steps": steps, "warmup": ARGS.warmup, "settle_steps": timer.settle_steps,
+            "value": value, "unit": "proposals/s", "n_gpus": world, "steps": steps, "warmup": ARGS.warmup,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 positions, f64 cost, i128 fixed-point sums", "data": "synthetic",
             "config": {"workload": f"{shape}: {n}-node spatial graph x {R} replicas"
