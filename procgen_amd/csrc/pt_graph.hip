@@ -398,13 +398,14 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         if (block == 1024 && N <= 16 * 768 && e->Ecap <= 32 * 768) block = 768;
         // Many more replicas than CUs: the device is kept busy by the number of workgroups, and every
         // wave of a workgroup repeats the per-step fixed work, so the smallest workgroup that still
-        // holds a replica's edges (24 per thread) and caches its nodes (16 per thread) runs fastest
-        // (1k-node graphs x 8192 replicas: 128 threads give 1.6x the rate of 256).
+        // holds a replica's edges (32 per thread in the variant such workgroups get) and caches its nodes (16 per
+        // thread) runs fastest (1k-node graphs x 8192 replicas: 256 threads 89 M proposals/s, 192 threads 112 M,
+        // 128 threads 142 M, 64 threads -- one wave per replica -- 163 M).
         hipDeviceProp_t prop;
         int cus = 0;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount; else (void)hipGetLastError();
         if (cus > 0 && (long long)e->R >= 2ll * cus) {
-            const int small = std::max((N + 15) / 16, (e->Ecap + 23) / 24);
+            const int small = std::max((N + 15) / 16, (e->Ecap + 31) / 32);
             block = std::min(block, std::max(64, (small + 63) / 64 * 64));
         }
     }
