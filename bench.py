@@ -12,7 +12,10 @@ sums are updated by the terms the move changes, which yields bit for bit the cos
 yields (--full-evaluation times the full re-evaluation kernels).  Without --steps the timed region is
 sized to last about 0.6 s.
 
-Multi-GPU (one process per GPU, launched by torch.distributed.run):
+Multi-GPU: one process per GPU.  Started under torch.distributed.run (RANK / WORLD_SIZE in the environment) this
+process is one rank; started plainly as `python bench.py --gpus N` with N > 1 it starts the N ranks itself
+(a child `python -m torch.distributed.run --nproc-per-node N bench.py ...`, before anything here touches the
+GPU) and passes on their output and exit code.
   default          every rank runs its own ladder: independent chains shard across GPUs with no
                    data-path collective; the whole-job value is the sum over ranks divided by the slowest
                    rank's time ("weak").
@@ -465,8 +468,24 @@ def main():
         dist.destroy_process_group()
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: run the N ranks as a child process and relay the result."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
 if __name__ == "__main__":
     ARGS = parse()
+    if ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(ARGS.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != max(ARGS.gpus, 1):
+        sys.exit(f"bench.py: --gpus {ARGS.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')} ranks")
     if ARGS.workload == "chunks":
         main_chunks()
     else:

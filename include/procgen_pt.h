@@ -80,9 +80,19 @@ void parallel_tempering_step(double *positions, int *edges, double *costs, doubl
 void parallel_tempering_step_f32(float *positions, int *edges, float *costs, float *temperatures,
                                  int nodeCount, int edgeCount, int tempCount);
 
-/* Drop the legacy entry points' persistent state (the reference never frees
- * its static device buffers, src/gpu/parallel_tempering.cu:139-146). */
+/* Drop the legacy entry points' persistent state, collision_detection's work memory included (the reference
+ * never frees its static device buffers, src/gpu/parallel_tempering.cu:139-146).
+ * Nothing of the caller's arrays is retained after parallel_tempering_step returns.  The one exception is
+ * opt-in: with PROCGEN_PT_PIN_CALLER_ARRAY=1 in the environment the positions array is page-locked
+ * (hipHostRegister) once the same array has come twice in a row and stays so until a different array comes or
+ * this function is called; a host that sets it must keep the array alive until then and call this function
+ * before freeing it. */
 void parallel_tempering_reset(void);
+
+/* Free the device work memory collision_detection / collision_detection_f32 keep between calls (it grows to the
+ * largest call's needs; a pair list above 64 MiB is freed when its call ends anyway).  No counterpart in the
+ * reference, which allocates and frees per call (src/gpu/collision_detection.cu:60-117). */
+void pt_collision_release(void);
 
 /* Replaces the reference export of the same name (reference src/GPU.Compute.fs:42-49, caller
  * src/GPU.Wrappers.fs:347-416): all pairs i < j with 0.001 < |p_j - p_i| < minDistance (fp32 distance,
@@ -106,9 +116,14 @@ void collision_detection_f32(const float *positions, int *collision_pairs, int n
  *                 (i, j) order
  *   d_count       one int, device: min(found, pair_capacity)
  *   stream        a hipStream_t (NULL: the default stream); the call returns once the work is queued
- * node_count above PT_COLLISION_DEVICE_MAX_NODES is refused with PT_ERR_INVALID_ARGUMENT.
+ * node_count above PT_COLLISION_DEVICE_MAX_NODES and pair_capacity above INT_MAX are refused with
+ * PT_ERR_INVALID_ARGUMENT.
  * All calls on one GPU share the work array: calls that overlap in time on one GPU (two streams, two
- * threads) race; queue them on one stream or order them with events. */
+ * threads, a captured graph replayed beside any other call) race; queue them on one stream or order them
+ * with events.
+ * Under stream capture: the first call on a GPU takes a host lock and asks the runtime for the array's address
+ * (hipGetSymbolAddress, which may load the code object) -- make one eager call per GPU, any size, before
+ * capturing. */
 #define PT_COLLISION_DEVICE_MAX_NODES 32768
 int pt_collision_detect_device(const float *d_positions, int node_count, float min_distance, int *d_pairs,
                                long long pair_capacity, int *d_count, void *stream);
@@ -196,7 +211,8 @@ int pt_graph_set_draws(pt_graph_engine *e, const double *chain_u, int64_t steps,
 /* Per-ladder Philox keys, keys [G]: ladder g then draws from keys[g] with the temperature slot as the
  * stream id (and swap stream 0), so that a ladder's trajectory does not depend on its index in the
  * batch (e.g. keys[g] = pt_hash_coordinates(pt_seed_key(seed), x, y, z)).  Without this call all ladders
- * share the engine's key and differ by stream id.  Call before pt_graph_run. */
+ * share the engine's key and differ by stream id.  Call before the first step of a run: once a step has
+ * run since the last upload the call fails with PT_ERR_INVALID_ARGUMENT (streams do not change in mid-run). */
 int pt_graph_set_ladder_keys(pt_graph_engine *e, const uint64_t *keys);
 
 /* Optional per-step trace for parity tests: records [max_steps][G*T] of
@@ -372,7 +388,8 @@ int pt_chunk_upload(pt_chunk_engine *e, const float *density, const float *moist
  * (the chunk seed of reference src/Terrain.Generation.fs:172-176) with its temperature slot as the stream
  * id, so its trajectory depends on (seed, position) and not on where in the batch it sits.  Without this
  * call all chunks share the engine's key and chunk g draws from stream (group_base + g) * T + slot.
- * pt_chunk_set_ladder_keys gives the per-chunk keys directly.  Call before pt_chunk_run. */
+ * pt_chunk_set_ladder_keys gives the per-chunk keys directly.  Call before the first step of a run: after
+ * steps have run since the last upload both calls fail with PT_ERR_INVALID_ARGUMENT. */
 int pt_chunk_set_positions(pt_chunk_engine *e, const int32_t *xyz);
 int pt_chunk_set_ladder_keys(pt_chunk_engine *e, const uint64_t *keys);
 /* injected draws: chain_u [G][T][steps][8], swap_u [G][passes][T-1] */
@@ -390,6 +407,12 @@ int pt_chunk_replica_slots(pt_chunk_engine *e, int32_t *slot_of_replica);
 int pt_chunk_cost_terms(pt_chunk_engine *e, double *terms);
 int pt_chunk_get_stats(pt_chunk_engine *e, pt_graph_stats *out);
 int pt_chunk_kernel_time(pt_chunk_engine *e, double *ms, int64_t *launches, int32_t reset);
+/* How the step kernel is launched for this engine's replica count: lanes per workgroup (64 or 256) and how many
+ * of them hold a replica (the other lanes of a 64-lane workgroup assist: shared draws, wave-wide cave search).
+ * The host picks it from the replica count and the device's compute units; PROCGEN_PT_CHUNK_RPB (a power of two,
+ * the fewest replicas per 64-lane workgroup) and PROCGEN_PT_CHUNK_WIDE=1 (256-lane workgroups), read at create
+ * time, let the parity tests run every route at small sizes.  Either pointer may be NULL. */
+int pt_chunk_launch_shape(pt_chunk_engine *e, int32_t *block_threads, int32_t *replicas_per_workgroup);
 
 /* Unit-test hook: the exact fixed-point sum the engine uses, over n doubles. */
 int pt_debug_canonical_sum(const double *terms, int64_t n, double *out, int32_t *range_error);

@@ -4,6 +4,7 @@
 #include "../../include/procgen_pt.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -18,9 +19,11 @@ struct LegacyState {
     std::vector<double> temps;
     std::vector<int32_t> ecount, edges;     // what the engine was last uploaded with
     bool uploaded = false;
-    // the caller's position array, page-locked once the same array has come twice in a row (the host's
-    // loop passes one pinned array for the whole job, reference src/GPU.Wrappers.fs:312-323): copies to and
-    // from it then run at the bus rate
+    // Opt-in (PROCGEN_PT_PIN_CALLER_ARRAY=1): the caller's position array is page-locked once the same array has
+    // come twice in a row (the host's loop passes one GC-pinned array for the whole job, reference
+    // src/GPU.Wrappers.fs:312-323), so that whole-array copies run at the bus rate.  The registration outlives the
+    // call, which is only safe when the caller keeps the array alive until parallel_tempering_reset() or until it
+    // passes a different array; by default nothing of the caller's memory is retained after a call returns.
     void *seen_ptr = nullptr;
     size_t seen_bytes = 0;
     int seen_count = 0;
@@ -39,8 +42,15 @@ void forget_array(LegacyState &s)
     s.registered = false; s.seen_ptr = nullptr; s.seen_bytes = 0; s.seen_count = 0;
 }
 
+bool pin_caller_array()
+{
+    static const bool on = [] { const char *v = std::getenv("PROCGEN_PT_PIN_CALLER_ARRAY"); return v && std::atoi(v) != 0; }();
+    return on;
+}
+
 void note_array(LegacyState &s, void *p, size_t bytes)
 {
+    if (!pin_caller_array()) return;
     if (p != s.seen_ptr || bytes != s.seen_bytes) { forget_array(s); s.seen_ptr = p; s.seen_bytes = bytes; }
     s.seen_count++;
     if (!s.registered && s.seen_count == 2) {
@@ -137,8 +147,11 @@ void parallel_tempering_step_f32(float *positions, int *edges, float *costs, flo
 void parallel_tempering_reset(void)
 {
     LegacyState &s = state();
-    std::lock_guard<std::mutex> lock(s.mu);
-    drop(s);
+    {
+        std::lock_guard<std::mutex> lock(s.mu);
+        drop(s);
+    }
+    pt_collision_release();
 }
 
 }  // extern "C"

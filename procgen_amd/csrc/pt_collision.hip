@@ -273,6 +273,7 @@ struct Workspace {
     GrowBuf pos, work, pairs;
 };
 Workspace g_ws;
+constexpr size_t RETAIN_PAIR_BYTES = (size_t)64 << 20;      // a larger pair list is freed when its call ends
 
 // pairs_out holds at most `capacity` pairs; *count receives the true number found
 int detect(const float *pos, int n, double min_distance, double eps, int *pairs_out, long long capacity, long long *count)
@@ -315,6 +316,8 @@ int detect(const float *pos, int n, double min_distance, double eps, int *pairs_
     { int rc = cd_launch_emit(P, st); if (rc) return rc; }
     PT_HIP_TRY(hipMemcpyAsync(pairs_out, g_ws.pairs.p, sizeof(int2) * (size_t)keep, hipMemcpyDeviceToHost, st));
     PT_HIP_TRY(hipStreamSynchronize(st));
+    // one dense call does not pin its pair list for the life of the process
+    if (g_ws.pairs.bytes > RETAIN_PAIR_BYTES) { (void)hipFree(g_ws.pairs.p); g_ws.pairs.p = nullptr; g_ws.pairs.bytes = 0; }
     return PT_OK;
 }
 
@@ -382,12 +385,27 @@ void collision_detection_f32(const float *positions, int *collision_pairs, int n
     entry<float>(positions, collision_pairs, node_count, min_distance, out_count);
 }
 
+void pt_collision_release(void)
+{
+    std::lock_guard<std::mutex> lock(g_ws.mu);
+    if (g_ws.device < 0) return;
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    if (hipSetDevice(g_ws.device) == hipSuccess)
+        for (GrowBuf *b : {&g_ws.pos, &g_ws.work, &g_ws.pairs}) { if (b->p) (void)hipFree(b->p); b->p = nullptr; b->bytes = 0; }
+    if (have_prev) (void)hipSetDevice(prev);
+    (void)hipGetLastError();
+    g_ws.device = -1;
+}
+
 int pt_collision_detect_device(const float *d_positions, int node_count, float min_distance, int *d_pairs,
                                long long pair_capacity, int *d_count, void *stream)
 {
     pt::clear_error();
     if (!d_positions || !d_count || node_count < 0 || pair_capacity < 0 || (pair_capacity > 0 && !d_pairs))
         return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null pointer or negative size");
+    if (pair_capacity > 0x7fffffffll)       // *d_count is an int
+        return pt::set_error(PT_ERR_INVALID_ARGUMENT, "pair_capacity above INT_MAX: the count is reported as an int");
     if (node_count > NOALLOC_MAX_NODES)
         return pt::set_error(PT_ERR_INVALID_ARGUMENT, "pt_collision_detect_device holds at most " + std::to_string(NOALLOC_MAX_NODES) +
                                                        " nodes in its fixed work memory; use collision_detection for more");

@@ -65,6 +65,7 @@ struct pt_graph_engine {
     bool relabel_forced = false;                            // test hook: rebuild at every interval, whatever the labels reached
     long long trace_steps = 0, trace_passes = 0;
     bool uploaded = false;
+    bool stepped = false;                      // a step kernel has run since the last upload (ladder keys are fixed from then on)
     std::mutex mu;
     // timing of the step kernel
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -136,6 +137,7 @@ int device_status(const void *d_status)
 
 int launch_steps(pt_graph_engine *e, long long step0, int nsteps)
 {
+    if (nsteps > 0) e->stepped = true;
     if (nsteps <= 0) return PT_OK;
     // The incremental kernels hand out discovery labels from a 32-bit counter that only grows (by at
     // most one per edge looked at in a step).  Long before it can wrap, the state they continue from is
@@ -807,6 +809,7 @@ int pt_graph_upload(pt_graph_engine *e, const float *positions, const int32_t *e
     { int rc = launch_init(e, e->P, 1); if (rc) return rc; }
     PT_HIP_TRY(hipStreamSynchronize(st));
     e->uploaded = true;
+    e->stepped = false;
     return device_status(e->status.p);      // an initial cost outside the exact sums' range
 }
 
@@ -833,6 +836,7 @@ int pt_graph_set_ladder_keys(pt_graph_engine *e, const uint64_t *keys)
     pt::clear_error();
     if (!e || !keys) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "null engine or keys");
     std::lock_guard<std::mutex> lock(e->mu);
+    if (e->stepped) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "ladder keys must be set before the first step of a run (upload again to start a new one)");
     DeviceGuard guard(e->device);
     PT_HIP_TRY(hipStreamSynchronize(e->stream));
     PT_HIP_TRY(e->group_keys.alloc(sizeof(uint64_t) * (size_t)e->G));

@@ -294,6 +294,12 @@ class ChunkEngine:
         return dict(steps=s.steps, proposals=s.proposals, accepted=s.accepted,
                     swap_attempts=s.swap_attempts, swaps=s.swaps, status_bits=s.status_bits)
 
+    def launch_shape(self):
+        """(lanes per workgroup, replicas per workgroup) of the step kernel."""
+        bt, rpb = C.c_int32(0), C.c_int32(0)
+        nt.check(self.L.pt_chunk_launch_shape(self.h, C.byref(bt), C.byref(rpb)))
+        return bt.value, rpb.value
+
     def kernel_time(self, reset=False):
         ms, n = C.c_double(0), C.c_int64(0)
         nt.check(self.L.pt_chunk_kernel_time(self.h, C.byref(ms), C.byref(n), int(reset)))

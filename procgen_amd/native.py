@@ -56,7 +56,7 @@ TRACE_DTYPE = np.dtype([("kind", "<i4"), ("a", "<i4"), ("b", "<i4"), ("flags", "
 EXPORTS = [
     "pt_last_error", "pt_last_error_string",
     "parallel_tempering_step", "parallel_tempering_step_f32", "parallel_tempering_reset",
-    "collision_detection", "collision_detection_f32", "pt_collision_detect_device",
+    "collision_detection", "collision_detection_f32", "pt_collision_detect_device", "pt_collision_release",
     "pt_graph_default_config", "pt_graph_create", "pt_graph_destroy", "pt_graph_upload",
     "pt_graph_set_draws", "pt_graph_enable_trace", "pt_graph_read_trace", "pt_graph_run",
     "pt_graph_sync", "pt_graph_set_step", "pt_graph_run_to_swap_point", "pt_graph_local_energy_ptr",
@@ -67,7 +67,7 @@ EXPORTS = [
     "pt_graph_set_ladder_keys", "pt_chunk_set_ladder_keys", "pt_chunk_set_positions",
     "pt_chunk_default_config", "pt_chunk_create", "pt_chunk_destroy", "pt_chunk_upload", "pt_chunk_set_draws",
     "pt_chunk_enable_trace", "pt_chunk_read_trace", "pt_chunk_run", "pt_chunk_sync", "pt_chunk_download",
-    "pt_chunk_replica_slots", "pt_chunk_cost_terms", "pt_chunk_get_stats", "pt_chunk_kernel_time",
+    "pt_chunk_replica_slots", "pt_chunk_cost_terms", "pt_chunk_get_stats", "pt_chunk_kernel_time", "pt_chunk_launch_shape",
 ]
 
 class ChunkConfig(C.Structure):
@@ -169,6 +169,8 @@ def load():
     L.collision_detection_f32.restype = None
     L.collision_detection_f32.argtypes = [vp, vp, i32, C.c_float, vp]
     L.pt_collision_detect_device.argtypes = [vp, i32, C.c_float, vp, C.c_longlong, vp, vp]
+    L.pt_collision_release.restype = None
+    L.pt_collision_release.argtypes = []
     L.pt_chunk_default_config.restype = None
     L.pt_chunk_default_config.argtypes = [C.POINTER(ChunkConfig), i32, i32]
     L.pt_chunk_create.argtypes = [C.POINTER(ChunkConfig), C.POINTER(vp)]
@@ -185,6 +187,7 @@ def load():
     L.pt_chunk_cost_terms.argtypes = [vp, vp]
     L.pt_chunk_get_stats.argtypes = [vp, C.POINTER(GraphStats)]
     L.pt_chunk_kernel_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64), i32]
+    L.pt_chunk_launch_shape.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.pt_geometric_ladder.restype = C.c_int
     L.pt_geometric_ladder.argtypes = [dbl, dbl, i32, C.POINTER(dbl)]
     L.pt_swap_frequency.restype = i32

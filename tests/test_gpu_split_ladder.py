@@ -102,3 +102,28 @@ def test_bench_split_ladder_rehearsal_two_ranks(gpu_lib):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["energy_gathers"] == rec["steps"] == 3
     assert rec["config"]["backend"].startswith("gloo") and rec["value"] > 0
+
+
+@pytest.mark.parametrize("mode", ["ladders-per-rank", "split-ladder"])
+def test_bench_starts_its_own_ranks(gpu_lib, mode):
+    """Plain `python bench.py --gpus 2` (no launcher around it) starts two ranks itself and prints one line for the
+    whole job; rehearsed on this one GPU over gloo."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PROCGEN_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--nodes", "3000", "--replicas", "4", "--steps", "3",
+           "--warmup", "1", "--no-cpu-baseline"] + (["--split-ladder"] if mode == "split-ladder" else [])
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["value"] > 0
+    assert rec["config"]["backend"].startswith("gloo")
+    if mode == "split-ladder":
+        assert rec["config"]["energy_gathers"] == 3
