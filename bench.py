@@ -405,18 +405,21 @@ def main():
                                      "frac_of_peak_issue": lane_instr / (FP32_VALU_PEAK_TFLOPS * 1e12 / 2.0),
                                      "note": "rocprofv3 --pmc SQ_INSTS_* of one launch (profiles/pmc_sq.json) over this run's "
                                              "launch time; 64 of 256 CUs hold a replica"}
-                    # what the SIMDs that hold a replica could issue, as measured on this chip (scripts/instr_rate.hip: with
-                    # every wave of a SIMD timed to its end, a SIMD retires one packed-fp32 / fp64 / integer / DPP instruction
-                    # per 4.4 s_memtime ticks, one plain fp32 instruction per 3.0; the counter runs at 1.42 ticks per ns)
-                    simds = 4.0 * min(R * G, 256)
-                    per_simd = sq["SQ_INSTS_VALU"] / launch_s / simds
-                    cap = 1.42e9 / 4.4
-                    measured_valu["issue_on_simds_in_use"] = {
-                        "valu_wave_instructions_per_s_per_simd": per_simd, "measured_capacity_per_s_per_simd": cap,
-                        "frac": per_simd / cap,
-                        "note": "VALU wave-instructions per second on each of the 256 SIMDs of the 64 CUs that hold a replica, against "
-                                "the rate at which one SIMD retires this instruction mix when saturated (microbenchmark, "
-                                "scripts/instr_rate.hip); the serial stretches of a step (one wave) are inside the time"}
+                    # Share of the time in which the SIMDs that hold a replica have a vector instruction in flight, from the
+                    # counters alone: SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES both count quad-cycles, the second summed over
+                    # the waves, so their ratio is one wave's share and `waves_per_simd` of them share a SIMD.
+                    waves_per_simd = info["block_threads"] / 64.0 / 4.0
+                    if sq.get("SQ_WAVE_CYCLES"):
+                        measured_valu["valu_busy_on_simds_in_use"] = {
+                            "frac": sq["SQ_ACTIVE_INST_VALU"] * waves_per_simd / sq["SQ_WAVE_CYCLES"],
+                            "waves_per_simd": waves_per_simd,
+                            "quad_cycles_per_valu_instruction": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_INSTS_VALU"],
+                            "note": "SQ_ACTIVE_INST_VALU x waves per SIMD / SQ_WAVE_CYCLES (profiles/pmc_sq.json; clock-free: "
+                                    "both are quad-cycle counts).  The counter books one quad-cycle per instruction whatever it "
+                                    "is; a saturated SIMD retires this kernel's mix (packed fp32, fp64, conversions, DPP) more "
+                                    "slowly than that (profiles/r03_instr_rate.txt), so the SIMDs are fuller than this figure "
+                                    "says and emptier than the instruction-rate estimate: the serial stretches of a step "
+                                    "(one wave at work) are where the empty slots sit"}
                 except (OSError, ValueError, KeyError):
                     pass
             roofline = dict(common, bound="valu", achieved=valu, peak=FP32_VALU_PEAK_TFLOPS, unit="TFLOP/s",

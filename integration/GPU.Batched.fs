@@ -1,7 +1,10 @@
 /// Host-side glue for the batched engine of libgpu_compute.so: what a maintainer of the reference adds
 /// next to src/GPU.Compute.fs / src/GPU.Wrappers.fs to run a whole parallel-tempering job in ONE native
 /// call (replacing the per-iteration loop of GPUTempering.optimize, src/GPU.Wrappers.fs:271-344, and
-/// the dispatch of src/GPU.Wrappers.fs:696-753).  NOT compiled in this repository's image (no .NET SDK
+/// the dispatch of src/GPU.Wrappers.fs:696-753), and, in module TerrainBatched below, to run
+/// Terrain.Generation.generate (src/Terrain.Generation.fs:172-199) for a whole batch of chunks on the voxel-chunk
+/// engine.  (TerrainBatched uses Voxel and Terrain types: it belongs in a file of Terrain.fsproj, after
+/// Terrain.Generation.fs; it is kept here so that the glue is in one place.)  NOT compiled in this repository's image (no .NET SDK
 /// there); the C ABI it binds is include/procgen_pt.h and is exercised through the same entry points
 /// by procgen_amd/native.py.
 namespace GPU
@@ -152,3 +155,120 @@ module Batched =
           Convergence.SwapAcceptanceRate = m.SwapAcceptanceRate
           Convergence.HasConverged = (m.HasConverged <> 0)
           Convergence.Iteration = m.Iteration }
+
+
+/// Terrain.Generation.generate (src/Terrain.Generation.fs:172-199) for a batch of chunks in one engine: every chunk's
+/// ladder (geometricLadder 0.1 5.0 6, swap every 50) runs on the GPU, the chunk seed hashCoordinates seed x y z keys its
+/// random streams, and the lowest-cost replica of every ladder comes back (ParallelTempering.getBest, :196).
+/// The native side is driven in this order (integration/abi_harness.c replays exactly this sequence from C and
+/// tests/test_abi_harness.py compares what it prints with the CPU restatement of the terrain path):
+///   pt_chunk_default_config -> pt_chunk_create -> pt_chunk_upload -> pt_chunk_set_positions -> pt_chunk_run
+///   -> pt_chunk_download -> pt_chunk_destroy
+module TerrainBatched =
+
+    open Voxel
+    open Terrain
+
+    [<Struct; StructLayout(LayoutKind.Sequential)>]
+    type PtChunkConfig =
+        val mutable struct_size: int
+        val mutable temp_count: int
+        val mutable group_count: int
+        val mutable swap_frequency: int       // <= 0: 50
+        val mutable rng_mode: int
+        val mutable device: int
+        val mutable group_base: int
+        val mutable flags: int
+        [<MarshalAs(UnmanagedType.ByValArray, SizeConst = 8)>]
+        val mutable weights: float[]          // traversability, geological, overhang, erosion, aesthetics, caves, performance, biomeTransition
+        val mutable density_mutation_scale: float32
+        val mutable solid_to_air_threshold: float32
+        val mutable refinement_probability: float
+        val mutable philox_key: uint64        // the generation seed: chunk keys are hashCoordinates of it
+        val mutable seed: nativeint           // UTF-8 char*; 0 here (the key is given as a number)
+
+    [<Literal>]
+    let private Lib = "libgpu_compute.so"
+
+    [<DllImport(Lib, CallingConvention = CallingConvention.Cdecl)>]
+    extern void pt_chunk_default_config(PtChunkConfig& cfg, int tempCount, int groupCount)
+    [<DllImport(Lib, CallingConvention = CallingConvention.Cdecl)>]
+    extern int pt_chunk_create(PtChunkConfig& cfg, nativeint& engine)
+    [<DllImport(Lib, CallingConvention = CallingConvention.Cdecl)>]
+    extern void pt_chunk_destroy(nativeint engine)
+    [<DllImport(Lib, CallingConvention = CallingConvention.Cdecl)>]
+    extern int pt_chunk_upload(nativeint engine, float32[] density, float32[] moisture, float32[] temperature,
+                               byte[] material, float[] temperatures)
+    [<DllImport(Lib, CallingConvention = CallingConvention.Cdecl)>]
+    extern int pt_chunk_set_positions(nativeint engine, int[] xyz)
+    [<DllImport(Lib, CallingConvention = CallingConvention.Cdecl)>]
+    extern int pt_chunk_run(nativeint engine, int64 steps)
+    [<DllImport(Lib, CallingConvention = CallingConvention.Cdecl)>]
+    extern int pt_chunk_download(nativeint engine, float32[] density, float32[] moisture, float32[] temperature, float[] costs)
+    [<DllImport(Lib, CallingConvention = CallingConvention.Cdecl)>]
+    extern nativeint pt_last_error_string()
+
+    let private check (rc: int) =
+        if rc <> 0 then
+            failwithf "libgpu_compute: %s (code %d)" (Marshal.PtrToStringUTF8(pt_last_error_string())) rc
+
+    /// `initial`: the chunks as Generation.initializeFromNoise leaves them (src/Terrain.Generation.fs:85-120), one per
+    /// position; the noise stays on the host.  Returns the optimised chunks in the same order.
+    let generateFrom (initial: VoxelChunk array) (seed: uint64) (iterations: int) : VoxelChunk array =
+        let pt = Generation.getPTConfig ()
+        let mc = Generation.getMutationConfig ()
+        let g = initial.Length
+        let t = pt.TemperatureCount
+        let v = ChunkSize.resolution * ChunkSize.resolution * ChunkSize.resolution
+        let mutable cfg = PtChunkConfig()
+        pt_chunk_default_config(&cfg, t, g)
+        cfg.swap_frequency <- pt.SwapFrequency
+        cfg.density_mutation_scale <- mc.DensityMutationScale
+        cfg.solid_to_air_threshold <- mc.SolidToAirThreshold
+        cfg.refinement_probability <- mc.RefinementProbability
+        cfg.philox_key <- seed
+        let mutable engine = 0n
+        check (pt_chunk_create(&cfg, &engine))
+        try
+            // every temperature of a ladder starts from the same chunk (src/Terrain.Generation.fs:181-182)
+            let density = Array.zeroCreate<float32> (g * t * v)
+            let moisture = Array.zeroCreate<float32> (g * t * v)
+            let temperature = Array.zeroCreate<float32> (g * t * v)
+            let material = Array.zeroCreate<byte> (g * v)
+            let xyz = Array.zeroCreate<int> (g * 3)
+            initial |> Array.iteri (fun c chunk ->
+                chunk.Graph.Nodes |> Array.iteri (fun i (n: VoxelData) ->
+                    material.[c * v + i] <- n.Material
+                    for k in 0 .. t - 1 do
+                        let at = (c * t + k) * v + i
+                        density.[at] <- n.Density
+                        moisture.[at] <- n.Moisture
+                        temperature.[at] <- n.Temperature)
+                xyz.[c * 3] <- chunk.Position.X
+                xyz.[c * 3 + 1] <- chunk.Position.Y
+                xyz.[c * 3 + 2] <- chunk.Position.Z)
+            let ladder = ParallelTempering.geometricLadder pt.MinTemperature pt.MaxTemperature t
+            let temps = Array.init (g * t) (fun k -> ladder.[k % t])
+            check (pt_chunk_upload(engine, density, moisture, temperature, material, temps))
+            check (pt_chunk_set_positions(engine, xyz))
+            check (pt_chunk_run(engine, int64 iterations))
+            let costs = Array.zeroCreate<float> (g * t)
+            check (pt_chunk_download(engine, density, moisture, temperature, costs))
+            initial |> Array.mapi (fun c chunk ->
+                // ParallelTempering.getBest (src/ParallelTempering.Core.fs:218-221): the first chain of lowest cost
+                let best = [| 0 .. t - 1 |] |> Array.minBy (fun k -> costs.[c * t + k])
+                let nodes =
+                    chunk.Graph.Nodes |> Array.mapi (fun i n ->
+                        let at = (c * t + best) * v + i
+                        { n with Density = density.[at]; Moisture = moisture.[at]; Temperature = temperature.[at] })
+                { chunk with Graph = { chunk.Graph with Nodes = nodes } })
+        finally
+            pt_chunk_destroy engine
+
+    /// Drop-in for a loop of Generation.generate calls (src/Terrain.Generation.fs:172-199) over `positions`.
+    let generate (positions: ChunkPosition array) (seed: uint64) (iterations: int) : VoxelChunk array =
+        let initial =
+            positions |> Array.map (fun pos ->
+                let chunkSeed = Deterministic.DeterministicGeneration.hashCoordinates seed pos.X pos.Y pos.Z
+                Generation.initializeFromNoise pos chunkSeed Noise.Presets.mountainous)
+        generateFrom initial seed iterations

@@ -12,12 +12,17 @@
  *   - it replays the call sequences of GPU.Wrappers.fs: the availability probe (:109-120), the
  *     per-iteration loop of GPUTempering.optimize (:291-342), GPUCollision.detect (:347-416), and the
  *     check_convergence_async extern (src/GPU.Compute.fs:98-109) with a 4-byte-bool swap history;
- *   - it then drives the batched engine the way integration/GPU.Batched.fs does.
+ *   - it then drives the batched engine the way integration/GPU.Batched.fs does, and the voxel-chunk engine the
+ *     way its TerrainBatched.generateFrom does for Terrain.Generation.generate (reference
+ *     src/Terrain.Generation.fs:172-199): create, upload one ladder per chunk, chunk positions, run, download.
  *
  * usage: abi_harness <path to libgpu_compute.so> [--layout-only | --dump <file>]
  *   --layout-only   load, bind, probe; no call that needs a GPU
  *   --dump <file>   also write the job's inputs (int32 N, T, E, iterations; positions [T][N][3], temperatures
- *                   [T] as doubles; edges [E][2] int32) so that a checker can run the same job elsewhere
+ *                   [T] as doubles; edges [E][2] int32) so that a checker can run the same job elsewhere, and
+ *                   to <file>.chunks the terrain job's (int32 chunks, T, iterations, swap frequency; uint64 seed;
+ *                   int32 xyz [chunks][3]; float32 density, moisture, temperature [chunks][32768]; uint8 material
+ *                   [chunks][32768]; double temperatures [T])
  * Prints one line per phase and ABI_HARNESS_OK at the end; any failure exits non-zero.
  */
 #include <dlfcn.h>
@@ -216,6 +221,80 @@ int main(int argc, char **argv)
         printf(" edges");
         for (int t = 0; t < T; t++) printf(" %d", ecount[t]);
         printf("\n");
+    }
+    /* ---- the voxel-chunk engine, as TerrainBatched.generateFrom of integration/GPU.Batched.fs drives it ---- */
+    {
+        enum { CHUNKS = 2, CT = 6, V = PT_CHUNK_VOXELS, CITERS = 200 };
+        void (*cdef)(pt_chunk_config *, int32_t, int32_t) = (void (*)(pt_chunk_config *, int32_t, int32_t))must("pt_chunk_default_config");
+        int (*ccreate)(const pt_chunk_config *, pt_chunk_engine **) = (int (*)(const pt_chunk_config *, pt_chunk_engine **))must("pt_chunk_create");
+        int (*cupload)(pt_chunk_engine *, const float *, const float *, const float *, const uint8_t *, const double *) =
+            (int (*)(pt_chunk_engine *, const float *, const float *, const float *, const uint8_t *, const double *))must("pt_chunk_upload");
+        int (*cpos)(pt_chunk_engine *, const int32_t *) = (int (*)(pt_chunk_engine *, const int32_t *))must("pt_chunk_set_positions");
+        int (*crun)(pt_chunk_engine *, int64_t) = (int (*)(pt_chunk_engine *, int64_t))must("pt_chunk_run");
+        int (*cdown)(pt_chunk_engine *, float *, float *, float *, double *) =
+            (int (*)(pt_chunk_engine *, float *, float *, float *, double *))must("pt_chunk_download");
+        void (*cdestroy)(pt_chunk_engine *) = (void (*)(pt_chunk_engine *))must("pt_chunk_destroy");
+        int (*ladder)(double, double, int32_t, double *) = (int (*)(double, double, int32_t, double *))must("pt_geometric_ladder");
+        const uint64_t seed = 0x5eedf00d12345678ull;                 /* Generation.generate's `seed: uint64` */
+        static const int32_t xyz[CHUNKS * 3] = {3, -1, 7, 0, 0, 0};  /* ChunkPosition X, Y, Z */
+        float *den = malloc(sizeof(float) * CHUNKS * CT * V), *moi = malloc(sizeof(float) * CHUNKS * CT * V),
+              *tem = malloc(sizeof(float) * CHUNKS * CT * V);
+        uint8_t *mat = malloc((size_t)CHUNKS * V);
+        static double ctemps[CHUNKS * CT], ccost[CHUNKS * CT];
+        if (!den || !moi || !tem || !mat) FAIL("out of memory");
+        if (ladder(0.1, 5.0, CT, ctemps) != CT) FAIL("pt_geometric_ladder");     /* src/Terrain.Generation.fs:18-23, :181 */
+        for (int c = 1; c < CHUNKS; c++) memcpy(ctemps + c * CT, ctemps, sizeof(double) * CT);
+        /* a stand-in for initializeFromNoise (the noise stays on the host): a sloped surface with air pockets below */
+        for (int c = 0; c < CHUNKS; c++)
+            for (int i = 0; i < V; i++) {
+                const int x = i & 31, y = (i >> 5) & 31, z = i >> 10;
+                const double h = 10.0 + 6.0 * rnd() * 0.1 + 0.25 * x + (c ? 0.2 * z : -0.1 * z);
+                float d = (double)y < h ? 1.0f : 0.0f;
+                if (y <= 16 && rnd() < 0.04) d = 0.0f;
+                const float m = (float)rnd(), tt = (float)(rnd() * 40.0 - 10.0);
+                mat[(size_t)c * V + i] = (uint8_t)(d > 0.5f ? (y > 12 ? 2 : 1) + (m > 0.7f) : 0);
+                for (int k = 0; k < CT; k++) {                       /* every temperature starts from the same chunk (:181-182) */
+                    const size_t at = ((size_t)c * CT + k) * V + i;
+                    den[at] = d; moi[at] = m; tem[at] = tt;
+                }
+            }
+        if (dump) {
+            char name[4096];
+            snprintf(name, sizeof name, "%s.chunks", dump);
+            FILE *fh = fopen(name, "wb");
+            const int32_t hdr[4] = {CHUNKS, CT, CITERS, 50};
+            int ok = fh && fwrite(hdr, sizeof hdr, 1, fh) == 1 && fwrite(&seed, sizeof seed, 1, fh) == 1 && fwrite(xyz, sizeof xyz, 1, fh) == 1;
+            for (int f = 0; ok && f < 3; f++) {
+                const float *src = f == 0 ? den : (f == 1 ? moi : tem);
+                for (int c = 0; ok && c < CHUNKS; c++) ok = fwrite(src + (size_t)c * CT * V, sizeof(float), V, fh) == V;
+            }
+            ok = ok && fwrite(mat, 1, (size_t)CHUNKS * V, fh) == (size_t)CHUNKS * V && fwrite(ctemps, sizeof(double), CT, fh) == CT;
+            if (!ok || fclose(fh) != 0) FAIL("cannot write %s", name);
+        }
+        pt_chunk_config cc;
+        cdef(&cc, CT, CHUNKS);
+        cc.swap_frequency = 50;                                      /* ptConfig.SwapFrequency */
+        cc.philox_key = seed;
+        pt_chunk_engine *ce = NULL;
+        if (ccreate(&cc, &ce) != PT_OK) FAIL("pt_chunk_create: %s", last_error_string());
+        if (cupload(ce, den, moi, tem, mat, ctemps) != PT_OK) FAIL("pt_chunk_upload: %s", last_error_string());
+        if (cpos(ce, xyz) != PT_OK) FAIL("pt_chunk_set_positions: %s", last_error_string());
+        if (crun(ce, CITERS) != PT_OK) FAIL("pt_chunk_run: %s", last_error_string());
+        if (cdown(ce, den, moi, tem, ccost) != PT_OK) FAIL("pt_chunk_download: %s", last_error_string());
+        cdestroy(ce);
+        printf("terrain: %d chunks x %d iterations, costs", CHUNKS, CITERS);
+        for (int k = 0; k < CHUNKS * CT; k++) { if (!isfinite(ccost[k])) FAIL("chunk cost %d", k); printf(" %a", ccost[k]); }
+        /* what TerrainBatched.generateFrom keeps: the first chain of lowest cost of every ladder, and its voxels */
+        printf(" best");
+        for (int c = 0; c < CHUNKS; c++) {
+            int best = 0;
+            for (int k = 1; k < CT; k++) if (ccost[c * CT + k] < ccost[c * CT + best]) best = k;
+            double sum = 0.0;
+            for (int i = 0; i < V; i++) sum += (double)den[((size_t)c * CT + best) * V + i];
+            printf(" %d:%a", best, sum);
+        }
+        printf("\n");
+        free(den); free(moi); free(tem); free(mat);
     }
     printf("ABI_HARNESS_OK\n");
     return 0;

@@ -1,9 +1,17 @@
 """Host-side mirror of the reference's seeded workload generators (src/Deterministic.fs).
 
-Same module and function names as the F# file, so that a job described by a seed string
-builds the same starting graph here as `DeterministicGeneration.createGraph` /
-`generateEdges` build there.  Everything is a pure function of the seed string:
+Same module and function names and the same formulas as the F# file: a job described by a seed
+string builds its starting graph here the way `DeterministicGeneration.createGraph` /
+`generateEdges` build it there.  Everything is a pure function of the seed string:
 `HashRNG` hashes utf8(seed + decimal(index)) with SHA-256 and reads the first eight bytes.
+
+How far "the same" goes.  `HashRNG` and `hashCoordinates` are integer and SHA-256 arithmetic:
+exact.  The point generators go through fp64 `cos` / `sin` (arguments up to 1e7 rad), `acos`
+and `pow`, taken here from the C library and there from .NET's `Math.*`; a one-ulp difference
+between the two can survive the rounding to fp32 in rare cases and then move a coordinate by one
+fp32 ulp or flip a `threshold < probability` edge decision.  The reference holds no output of
+these generators to check against, so their results are parity unpinned: equal to this
+repository's own restatement (oracle/pt_oracle.c), not claimed bit-identical to a .NET run.
 
 The optimisation loop of `DeterministicGeneration.generate` (src/Deterministic.fs:143-178)
 is not mirrored: its mutation seeds itself from `graph.GetHashCode()`, a .NET object

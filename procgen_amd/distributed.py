@@ -29,14 +29,28 @@ class GraphEngineShard:
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.stream = torch.cuda.ExternalStream(engine.stream())        # the engine's own HIP stream, as torch sees it
         self.staged = torch.zeros(self.ladder_count, dtype=torch.float64, device=self.device)
+        # the engine's energy buffer (device memory the engine owns for its whole life) as a tensor, without a copy
+        ptr, count = engine.local_energy_ptr()
+        assert count == self.local_count
+
+        class _Buffer:
+            __cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 3}
+        self._keep = _Buffer()
+        self.energy_view = torch.as_tensor(self._keep, device=self.device)
 
     def run_to_swap_point(self, max_steps):
         return self.engine.run_to_swap_point(max_steps)
 
     def local_energies(self, out):
-        """out: a host or a device tensor; the copy waits for the steps launched so far."""
+        """out: a host or a device tensor.  A device tensor is filled on torch's current stream, which is made to wait
+        for the engine's stream (the steps launched so far) on the device: the host does not wait, so the gather that
+        follows is queued at once.  A host tensor (gloo) needs the values on the host: that copy waits."""
         assert out.dtype == torch.float64 and out.numel() == self.local_count and out.is_contiguous()
-        self.engine.read_energies(out.data_ptr())
+        if out.is_cuda:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            out.copy_(self.energy_view, non_blocking=True)
+        else:
+            self.engine.read_energies(out.data_ptr())
 
     def swap_pass(self, all_energies):
         assert all_energies.dtype == torch.float64 and all_energies.numel() == self.ladder_count and all_energies.is_contiguous()

@@ -66,3 +66,30 @@ def test_host_call_sequences_from_c_match_the_oracle(gpu_lib, tmp_path):
     got_costs = [float.fromhex(t) for t in tail.split("edges")[0].split()]
     got_edges = [int(t) for t in tail.split("edges")[1].split()]
     assert got_costs == [float(c) for c in batched["cost"]] and got_edges == batched["ecount"].tolist()
+
+    # the terrain job (TerrainBatched.generateFrom's call sequence): costs, the chain kept and its voxels
+    import terrain_binding as tb
+    raw = open(dump + ".chunks", "rb").read()
+    chunks, CT, citers, cf = np.frombuffer(raw, np.int32, 4)
+    seed = int(np.frombuffer(raw, np.uint64, 1, 16)[0])
+    xyz = np.frombuffer(raw, np.int32, chunks * 3, 24).reshape(chunks, 3)
+    off, V = 24 + xyz.nbytes, nt.CHUNK_VOXELS
+    fields = []
+    for _ in range(3):
+        fields.append(np.frombuffer(raw, np.float32, chunks * V, off).reshape(chunks, V)); off += chunks * V * 4
+    mat = np.frombuffer(raw, np.uint8, chunks * V, off).reshape(chunks, V); off += chunks * V
+    ctemps = np.frombuffer(raw, np.float64, CT, off)
+    tail = lines["terrain"].split("costs")[1]
+    got_costs = np.array([float.fromhex(t) for t in tail.split("best")[0].split()]).reshape(chunks, CT)
+    got_best = [t.split(":") for t in tail.split("best")[1].split()]
+    cfg = tb.default_config(ob.SUM_CANONICAL)
+    for c in range(chunks):
+        key = int(ob.lib().og_hash_coordinates(seed, int(xyz[c, 0]), int(xyz[c, 1]), int(xyz[c, 2])))
+        tile = lambda a: np.ascontiguousarray(np.tile(a[c], (CT, 1)))     # noqa: E731
+        o = tb.run(tile(fields[0]), tile(fields[1]), tile(fields[2]), mat[c], ctemps.copy(), int(citers), int(cf), cfg,
+                   key=key, stream_base=0, swap_stream_id=0, trace=False)
+        assert o["err"] == 0
+        assert np.array_equal(got_costs[c], o["cost"]), (c, got_costs[c], o["cost"])
+        best = int(np.argmin(o["cost"]))
+        assert int(got_best[c][0]) == best
+        assert float.fromhex(got_best[c][1]) == float(o["density"][best].astype(np.float64).sum())

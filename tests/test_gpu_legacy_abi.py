@@ -163,3 +163,62 @@ def test_resident_chains_and_a_caller_that_edits_its_positions(gpu_lib):
     o3 = ob.run(before, ed, o1["ecount"], wl["kind"][0], wl["value"][0], temps, 1, f, cfg, key=key, trace=False, first_step=16)
     assert np.array_equal(pos.reshape(T, n, 3).astype(np.float32), o3["pos"]) and np.array_equal(costs, o3["cost"])
     gpu_lib.parallel_tempering_reset()
+
+
+_FREED_ARRAY_JOB = r"""
+import gc, os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import oracle_binding as ob
+from procgen_amd import native as nt
+L = nt.load()
+pin = os.environ.get("PROCGEN_PT_PIN_CALLER_ARRAY") == "1"
+n, T, E = 3000, 8, 4000                       # 576 KB of positions: malloc takes it from mmap and gives it back on free
+rng = np.random.default_rng(3)
+edges = np.ascontiguousarray(np.stack([np.arange(E) % n, (np.arange(E) * 7 + 1) % n], 1).astype(np.int32))
+temps = np.ascontiguousarray(nt.geometric_ladder(0.5, 5.0, T), np.float64)
+def job(calls):
+    pos = np.ascontiguousarray(np.tile(rng.uniform(0, 9, (1, n, 3)), (T, 1, 1)))
+    costs = np.zeros(T)
+    for _ in range(calls):
+        L.parallel_tempering_step(nt.ptr(pos), nt.ptr(edges), nt.ptr(costs), nt.ptr(temps), n, E, T)
+        assert L.pt_last_error() == 0, L.pt_last_error_string()
+    assert np.isfinite(costs).all() and (costs > 0).all()
+    return pos
+pos = job(3)                                  # the same array three times in a row
+if pin:
+    L.parallel_tempering_reset()              # the documented duty of a host that opted in
+del pos; gc.collect()
+# host allocations of the same size class follow: pageable buffers that may land where the array was
+for k in range(3):
+    pts = np.ascontiguousarray(rng.uniform(0, 6, (n, 3)).astype(np.float32).astype(np.float64))
+    pairs = np.zeros((n * n // 2, 2), np.int32)
+    count = np.zeros(1, np.int32)
+    L.collision_detection(nt.ptr(pts), nt.ptr(pairs), n, 0.5, nt.ptr(count))
+    assert L.pt_last_error() == 0, L.pt_last_error_string()
+    want = ob.collision_pairs(pts.astype(np.float32), 0.5)
+    assert count[0] == len(want) > 0 and np.array_equal(pairs[:count[0]], want), k
+    del pairs
+pos = job(2)                                  # a new job, new array
+print("FREED_ARRAY_OK")
+"""
+
+
+@pytest.mark.parametrize("pin", ["default", "opt-in pinning"])
+def test_callers_array_freed_between_jobs(gpu_lib, pin):
+    """The host only pins its positions array for the job (reference src/GPU.Wrappers.fs:312-325) and may free it
+    afterwards: nothing of it is retained by default, so later calls that stage through pageable host buffers
+    (collision_detection) and a new job run cleanly; with PROCGEN_PT_PIN_CALLER_ARRAY=1 the same holds once the
+    host has called parallel_tempering_reset before freeing."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("PROCGEN_PT_PIN_CALLER_ARRAY", None)
+    if pin != "default":
+        env["PROCGEN_PT_PIN_CALLER_ARRAY"] = "1"
+    out = subprocess.run([sys.executable, "-c", _FREED_ARRAY_JOB.format(root=root)], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0 and "FREED_ARRAY_OK" in out.stdout, out.stderr[-3000:]
