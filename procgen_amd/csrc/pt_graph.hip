@@ -1349,7 +1349,7 @@ int pt_graph_legacy_iteration(pt_graph_engine *e, void *positions, void *costs, 
 
 extern "C" {
 
-#ifdef PT_STAMPS
+#if defined(PT_STAMPS) || defined(PT_STAMPS_LIGHT)
 // diagnostic build only: read (and clear) the per-phase cycle totals, [4096][16]
 int pt_debug_read_stamps(unsigned long long *out, int clear)
 {

@@ -70,6 +70,14 @@ template <int OP> __global__ void k(double *out, unsigned long long *cyc, double
             if (OP == 25) { asm volatile("v_readlane_b32 s20, %0, 3" :: "v"(u0) : "s20"); asm volatile("v_readlane_b32 s21, %0, 5" :: "v"(u1) : "s21");
                             asm volatile("v_readlane_b32 s22, %0, 7" :: "v"(u2) : "s22"); asm volatile("v_readlane_b32 s23, %0, 9" :: "v"(u3) : "s23"); }
             if (OP == 26) { asm volatile("v_pk_mul_f32 %0, %0, %2\n v_add_f64 %1, %1, %3" : "+v"(a0), "+v"(a2) : "v"(a1), "v"(a3)); asm volatile("v_sqrt_f32 %0, %2\n v_cvt_f64_f32 %1, %3" : "=v"(f0), "=v"(a1) : "v"(f1), "v"(f2)); }
+            if (OP == 27) { asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(u0) : "v"(u1)); asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(u2) : "v"(u3));
+                            asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(u1) : "v"(u0)); asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(u3) : "v"(u2)); }
+            if (OP == 28) { asm volatile("v_xor_b32 %0, %0, %1" : "+v"(u0) : "v"(u1)); asm volatile("v_xor_b32 %0, %0, %1" : "+v"(u2) : "v"(u3));
+                            asm volatile("v_xor_b32 %0, %0, %1" : "+v"(u1) : "v"(u0)); asm volatile("v_xor_b32 %0, %0, %1" : "+v"(u3) : "v"(u2)); }
+            if (OP == 29) { asm volatile("v_xor_b32 %0, %2, %1\n v_pk_min_u16 %3, %3, %0" : "+v"(u0), "+v"(u1) : "v"(u2), "v"(u3));
+                            asm volatile("v_xor_b32 %0, %2, %1\n v_pk_min_u16 %3, %3, %0" : "+v"(u0), "+v"(u1) : "v"(u2), "v"(u3)); }
+            if (OP == 30) { asm volatile("v_xor_b32 %0, s20, %1\n v_pk_min_u16 %2, %2, %0" : "+v"(u0), "+v"(u1), "+v"(u3) :: "s20");
+                            asm volatile("v_xor_b32 %0, s20, %1\n v_pk_min_u16 %2, %2, %0" : "+v"(u0), "+v"(u2), "+v"(u3) :: "s20"); }
             if (OP == 14) { asm volatile("v_min_u32 %0, %0, %1" : "+v"(u0) : "v"(u1)); asm volatile("v_min_u32 %0, %0, %1" : "+v"(u2) : "v"(u3));
                             asm volatile("v_min_u32 %0, %0, %1" : "+v"(u1) : "v"(u0)); asm volatile("v_min_u32 %0, %0, %1" : "+v"(u3) : "v"(u2)); }
         }
@@ -101,6 +109,7 @@ int main()
     run<12>("v_cmp_gt_f64"); run<2>("v_trunc_f64"); run<3>("v_cvt_u32_f64"); run<4>("v_cvt_f64_u32"); run<5>("v_cvt_f64_f32");
     run<15>("v_pk_fma_f32"); run<17>("v_pk_add_f32"); run<16>("v_fma_f32"); run<18>("v_min3_u32");
     run<19>("v_ldexp_f64"); run<20>("v_cmp_lt_u64"); run<21>("v_add(c)_co_u32"); run<22>("v_cmp+cndmask"); run<23>("v_pk_fma 3src"); run<24>("v_fma_f64 3src");
+    run<27>("v_pk_min_u16"); run<28>("v_xor_b32"); run<29>("xor+pk_min chain"); run<30>("xor(sgpr)+pk_min");
     run<25>("v_readlane"); run<26>("mix pk/f64/sqrt/cvt");
     run<6>("v_sqrt_f32"); run<8>("v_lshlrev_b64"); run<9>("v_lshl_add_u64"); run<13>("v_mov_b32_dpp");
     return 0;

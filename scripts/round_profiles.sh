@@ -9,7 +9,13 @@ T=$1
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_prof -- python3 $R/bench.py > $R/gpurun_out/${T}_bench.json 2> $R/gpurun_out/${T}_bench.err
 cp $(ls $R/gpurun_out/${T}_prof/*/*kernel_stats.csv | head -1) $R/gpurun_out/${T}_kernel_stats.csv
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_prof_chunks -- python3 $R/bench.py --workload chunks --no-cpu-baseline > /dev/null 2> $R/gpurun_out/${T}_prof_chunks.err
+cp $(ls $R/gpurun_out/${T}_prof_chunks/*/*kernel_stats.csv | head -1) $R/gpurun_out/${T}_chunks_kernel_stats.csv
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_prof_1m -- python3 $R/bench.py --nodes 1000000 --replicas 16 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/${T}_prof_1m.err
+cp $(ls $R/gpurun_out/${T}_prof_1m/*/*kernel_stats.csv | head -1) $R/gpurun_out/${T}_1m_kernel_stats.csv
 cd $R
+# the round-end driver's own command line (20 timed intervals after 5)
+timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${T}_bench_driver_line.json 2> gpurun_out/${T}_bench_driver_line.err
 timeout -k 10 300 python3 bench.py --workload chunks > gpurun_out/${T}_bench_chunks.json 2> gpurun_out/${T}_bench_chunks.err
 timeout -k 10 400 python3 bench.py --nodes 1000000 --replicas 16 > gpurun_out/${T}_bench_config3_shape.json 2> gpurun_out/${T}_bench_config3.err
 timeout -k 10 400 python3 bench.py --nodes 1000 --replicas 16 --ladders 512 > gpurun_out/${T}_bench_config4_shape.json 2> gpurun_out/${T}_bench_config4.err
