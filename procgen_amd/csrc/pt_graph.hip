@@ -41,6 +41,7 @@ struct pt_graph_engine {
     int device = 0, block = 0;
     bool lds_mode = false;
     bool delta_mode = false;    // incremental evaluation (pt_graph_delta_kernel)
+    bool delta_lists = false;   // ... with per-node lists of incident edges (global memory) and their fill counts (LDS)
     bool big_mode = false;      // incremental evaluation in global memory (pt_graph_big_kernel)
     int CB = 1;                 // ... by that many workgroups per replica (pt_graph_bigc_kernel when > 1)
     int ept = 24;               // edges each thread of that kernel holds in registers (24: any workgroup size, 48: at most 512 threads)
@@ -436,8 +437,17 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
     if (!(cfg->flags & (PT_FLAG_GLOBAL_MEMORY_PLACEMENT | PT_FLAG_FULL_EVALUATION | PT_FLAG_STREAMING_INCREMENTAL)) && N < 65535 && cfg->cluster_size <= 1 &&
         (long long)e->Ecap <= (long long)e->ept * block) {
         const size_t Npad = ((size_t)N + 3) & ~(size_t)3;
-        const size_t need = sizeof(Shared) + Npad * 12 + (((size_t)N * 2 + 15) / 16) * 16 + 5 * ((((size_t)nwords * 4 + 15) / 16) * 16);
+        const size_t need = sizeof(Shared) + Npad * 12 + (((size_t)N * 2 + 15) / 16) * 16 + 5 * ((((size_t)nwords * 4 + 15) / 16) * 16) +
+                            sizeof(unsigned) * DELTA_CAND;
         if (need <= LDS_BUDGET) { e->delta_mode = true; e->delta_lds_bytes = need; }
+        // a byte per node for the fill counts of the per-node lists of incident edges, where that still fits
+        // (PROCGEN_PT_DELTA_LISTS=0 turns the lists off: the parity tests run both)
+        const size_t with_lists = need + (((size_t)N + 15) / 16) * 16;
+        const char *lv = std::getenv("PROCGEN_PT_DELTA_LISTS");
+        if (e->delta_mode && with_lists <= LDS_BUDGET && !(lv && std::atoi(lv) == 0) &&
+            sizeof(unsigned) * (size_t)R * N * DELTA_LIST <= ((size_t)8 << 30)) {
+            e->delta_lists = true; e->delta_lds_bytes = with_lists;
+        }
     }
 
     // When the LDS-resident incremental kernel cannot take the replica (too many nodes or edges) and
@@ -611,6 +621,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         A(e->dlabel, sizeof(unsigned) * (size_t)R * N); A(e->dlabscr, sizeof(unsigned) * (size_t)R * N);
         A(e->epk, sizeof(unsigned) * (size_t)R * e->ept * block);
     }
+    if (e->delta_lists) A(e->binc, sizeof(unsigned) * (size_t)R * N * DELTA_LIST);
     if (e->big_mode) {
         A(e->dacc, sizeof(fx128) * (size_t)R * ACC_COUNT);
         A(e->dreach, sizeof(int) * (size_t)R * 4);
@@ -694,6 +705,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         P.dacc = e->dacc.as<fx128>(); P.dreach = e->dreach.as<int>(); P.dvis = e->dvis.as<unsigned>();
         P.dparent = e->dparent.as<unsigned short>(); P.dparscr = e->dparscr.as<unsigned short>();
         P.epk = e->epk.as<unsigned>(); P.epk_stride = e->ept * block;
+        P.binc = e->delta_lists ? e->binc.as<unsigned>() : nullptr;
         P.dlabel = e->dlabel.as<unsigned>(); P.dlabscr = e->dlabscr.as<unsigned>();
     }
 
