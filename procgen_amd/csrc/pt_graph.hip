@@ -42,6 +42,7 @@ struct pt_graph_engine {
     bool lds_mode = false;
     bool delta_mode = false;    // incremental evaluation (pt_graph_delta_kernel)
     bool delta_lists = false;   // ... with per-node lists of incident edges (global memory) and their fill counts (LDS)
+    int walk[3] = {DELTA_WALK_MEMBERS, DELTA_CAND, DELTA_WALK_ROUNDS};  // bounds of the subtree walk through those lists: nodes, entering edges, round trips
     bool big_mode = false;      // incremental evaluation in global memory (pt_graph_big_kernel)
     int CB = 1;                 // ... by that many workgroups per replica (pt_graph_bigc_kernel when > 1)
     int ept = 24;               // edges each thread of that kernel holds in registers (24: any workgroup size, 48: at most 512 threads)
@@ -448,6 +449,16 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
             sizeof(unsigned) * (size_t)R * N * DELTA_LIST <= ((size_t)8 << 30)) {
             e->delta_lists = true; e->delta_lds_bytes = with_lists;
         }
+        // PROCGEN_PT_DELTA_WALK=members,entering,rounds narrows (or widens, up to the buffers' sizes) the bounds within
+        // which a cut-off subtree is walked through the lists; the parity tests use it to drive the fall-back paths
+        if (const char *wv = std::getenv("PROCGEN_PT_DELTA_WALK")) {
+            int m = 0, c = 0, k = 0;
+            if (std::sscanf(wv, "%d,%d,%d", &m, &c, &k) == 3) {
+                e->walk[0] = std::min(std::max(m, 0), DELTA_SUBTREE);
+                e->walk[1] = std::min(std::max(c, 0), DELTA_CAND);
+                e->walk[2] = std::max(k, 0);
+            }
+        }
     }
 
     // When the LDS-resident incremental kernel cannot take the replica (too many nodes or edges) and
@@ -706,6 +717,7 @@ int pt_graph_create(const pt_graph_config *cfg, pt_graph_engine **out)
         P.dparent = e->dparent.as<unsigned short>(); P.dparscr = e->dparscr.as<unsigned short>();
         P.epk = e->epk.as<unsigned>(); P.epk_stride = e->ept * block;
         P.binc = e->delta_lists ? e->binc.as<unsigned>() : nullptr;
+        P.walk_members = e->walk[0]; P.walk_entering = e->walk[1]; P.walk_rounds = e->walk[2];
         P.dlabel = e->dlabel.as<unsigned>(); P.dlabscr = e->dlabscr.as<unsigned>();
     }
 

@@ -96,6 +96,7 @@ struct GraphParams {
     struct BigComm *bcomm;      // [R] cluster records of that kernel
     unsigned *binc;             // [R][N][16]  that kernel's per-node lists of incident edges: (other end << 1) | (1 when the edge leaves the node)
     int *bdeg;                  // [R][N]  entries in use; above 16: the node's list overflowed and is not used
+    int walk_members, walk_entering, walk_rounds;   // pt_graph_delta_kernel: bounds of the walk of a cut-off subtree through the lists
     // convergence monitoring (null when off): cost of every chain after every step, a ring per chain
     double *conv_hist;          // [G][Tl][conv_window], step s at index s % conv_window
     int conv_window;

@@ -74,6 +74,11 @@ def main():
     if buf[2048:2048 + 64].sum() > 0:
         print('per-wave cycles (mean over replicas), fine stamps build:')
         print('  pass 1, from its start to its sums added:', np.round(buf[3072:3072 + R].astype(np.float64).mean(axis=0) / iters).astype(int).tolist())
+        for m, nm in enumerate(["pass 1: before the loop", "pass 1: the loop", "pass 1: near nodes listed", "pass 1: sums added",
+                                "pass 2: before the loop", "pass 2: the loop", "pass 2: sums added"]):
+            rows = buf[1024 + 64 * m:1024 + 64 * m + min(R, 64)].astype(np.float64)
+            if rows.sum() > 0:
+                print(f'    {nm:28s}', np.round(rows.mean(axis=0) / iters).astype(int).tolist())
         print('  pass 2, from the barrier to its sums added:', np.round(buf[2048:2048 + R].astype(np.float64).mean(axis=0) / iters).astype(int).tolist())
     eng.close()
 

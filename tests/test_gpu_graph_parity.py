@@ -241,6 +241,33 @@ def test_trace_parity_topology_cases(gpu_lib, case, flags):
     assert np.array_equal(gpu["terms"][0, :, 6], gpu["cost"][0])
 
 
+@pytest.mark.parametrize("case", ["near-tree", "fragments", "hub", "duplicates"])
+def test_incremental_kernel_without_incident_lists(gpu_lib, case, monkeypatch):
+    """The incremental kernel keeps per-node lists of incident edges where they fit; without them (PROCGEN_PT_DELTA_LISTS=0)
+    it prices a move from the edge registers and searches a cut-off subtree by pointer jumping: same trajectory."""
+    monkeypatch.setenv("PROCGEN_PT_DELTA_LISTS", "0")
+    wl = _topology_case(case)
+    iters, f = 600, 7
+    gpu = pu.gpu_run(wl, iters, f, seed=case, chunks=[250, 350])
+    orc = pu.oracle_run(wl, iters, f, seed=case)
+    pu.assert_same_run(wl, gpu, orc, iters)
+
+
+@pytest.mark.parametrize("walk", ["0,128,1024", "3,128,1024", "256,2,1024", "256,128,2", "256,128,1024"],
+                         ids=["never", "3-nodes", "2-entering-edges", "2-round-trips", "widest"])
+@pytest.mark.parametrize("case", ["near-tree", "fragments"])
+def test_subtree_walk_bounds_only_choose_the_search(gpu_lib, case, walk, monkeypatch):
+    """A subtree cut off by a removal is walked through the lists within bounds (nodes, edges that enter it, round trips);
+    beyond them the general search starts over.  Whatever the bounds, the trajectory is the oracle's."""
+    monkeypatch.setenv("PROCGEN_PT_DELTA_WALK", walk)
+    wl = _topology_case(case)
+    iters, f = 600, 7
+    gpu = pu.gpu_run(wl, iters, f, seed=case, chunks=[250, 350])
+    orc = pu.oracle_run(wl, iters, f, seed=case)
+    pu.assert_same_run(wl, gpu, orc, iters)
+    assert len(np.unique(gpu["trace"]["reach0"])) > 3
+
+
 @pytest.mark.parametrize("block", [512, 768, 1024])
 def test_trace_parity_incremental_kernel_variants(gpu_lib, block):
     """The incremental kernel holds 24, 32 or 48 edges per thread depending on the workgroup size."""
