@@ -414,6 +414,9 @@ int pt_chunk_kernel_time(pt_chunk_engine *e, double *ms, int64_t *launches, int3
  * time, let the parity tests run every route at small sizes.  Either pointer may be NULL. */
 int pt_chunk_launch_shape(pt_chunk_engine *e, int32_t *block_threads, int32_t *replicas_per_workgroup);
 
+/* Unit-test hook: the number of floats x in [lo, hi) (positive, normal) whose square root as the node passes compute it
+ * differs from the correctly rounded one.  The passes vouch for [2^-20, 2^24) before they use it. */
+int pt_debug_sqrt_check(float lo, float hi, uint64_t *mismatches);
 /* Unit-test hook: the exact fixed-point sum the engine uses, over n doubles. */
 int pt_debug_canonical_sum(const double *terms, int64_t n, double *out, int32_t *range_error);
 

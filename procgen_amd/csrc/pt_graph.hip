@@ -1387,6 +1387,27 @@ int pt_debug_read_stamps(unsigned long long *out, int clear)
 }
 #endif
 
+// unit-test hook: on how many floats x with lo <= x < hi (both positive and normal) the kernels' square root is not
+// the correctly rounded one
+int pt_debug_sqrt_check(float lo, float hi, uint64_t *mismatches)
+{
+    pt::clear_error();
+    if (!mismatches || !(lo > 0.0f) || !(hi >= lo) || !std::isfinite(hi)) return pt::set_error(PT_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (pt::device_count() < 1) return pt::set_error(PT_ERR_NO_DEVICE, "no HIP device");
+    unsigned blo, bhi;
+    std::memcpy(&blo, &lo, 4); std::memcpy(&bhi, &hi, 4);
+    DevBuf bad;
+    PT_HIP_TRY(bad.alloc(sizeof(unsigned long long)));
+    PT_HIP_TRY(hipMemset(bad.p, 0, sizeof(unsigned long long)));
+    hipLaunchKernelGGL(pt_debug_sqrt_kernel, dim3(4096), dim3(256), 0, 0, blo, bhi, bad.as<unsigned long long>());
+    PT_HIP_TRY(hipGetLastError());
+    PT_HIP_TRY(hipDeviceSynchronize());
+    unsigned long long h = 0;
+    PT_HIP_TRY(hipMemcpy(&h, bad.p, sizeof h, hipMemcpyDeviceToHost));
+    *mismatches = (uint64_t)h;
+    return PT_OK;
+}
+
 // unit-test hook: exact fx128 sum of n doubles on the device
 int pt_debug_canonical_sum(const double *terms, int64_t n, double *out, int32_t *range_error)
 {

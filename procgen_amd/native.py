@@ -61,7 +61,7 @@ EXPORTS = [
     "pt_graph_set_draws", "pt_graph_enable_trace", "pt_graph_read_trace", "pt_graph_run",
     "pt_graph_sync", "pt_graph_set_step", "pt_graph_run_to_swap_point", "pt_graph_local_energy_ptr",
     "pt_graph_swap_pass", "pt_graph_read_energies", "pt_graph_download", "pt_graph_replica_slots", "pt_graph_cost_terms",
-    "pt_graph_get_stats", "pt_graph_kernel_time", "pt_graph_stream", "pt_graph_info", "pt_debug_canonical_sum",
+    "pt_graph_get_stats", "pt_graph_kernel_time", "pt_graph_stream", "pt_graph_info", "pt_debug_canonical_sum", "pt_debug_sqrt_check",
     "pt_graph_enable_convergence", "pt_graph_check_convergence", "pt_graph_run_until_converged", "check_convergence_async",
     "pt_geometric_ladder", "pt_swap_frequency", "pt_seed_key", "pt_hash_coordinates",
     "pt_graph_set_ladder_keys", "pt_chunk_set_ladder_keys", "pt_chunk_set_positions",
@@ -159,6 +159,7 @@ def load():
     L.pt_graph_stream.restype = vp
     L.pt_graph_stream.argtypes = [vp]
     L.pt_debug_canonical_sum.argtypes = [vp, i64, C.POINTER(dbl), C.POINTER(i32)]
+    L.pt_debug_sqrt_check.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_uint64)]
     L.pt_graph_enable_convergence.argtypes = [vp, i32]
     L.pt_graph_check_convergence.argtypes = [vp, dbl, i32, vp]
     L.pt_graph_run_until_converged.argtypes = [vp, i64, i32, dbl, C.POINTER(i64), vp]

@@ -39,6 +39,20 @@ def _exact_sum_py(x):
     return float(fractions.Fraction(tot, 1 << 64))
 
 
+def test_square_root_of_the_node_passes_is_correctly_rounded_everywhere(gpu_lib):
+    """The node passes take distances through a reciprocal-root approximation and two fused multiply-adds after
+    vouching that the squared distance lies in [2^-20, 2^24): every float of that window (369 098 752 of them) is
+    compared on the device with (float)sqrt((double)x), the correctly rounded root (sqrtf of the reference's
+    Vector3.Distance, src/ParallelTempering.Core.fs:213, 236-240)."""
+    import ctypes as C
+    bad = C.c_uint64(12345)
+    assert gpu_lib.pt_debug_sqrt_check(C.c_float(2.0 ** -20), C.c_float(2.0 ** 24), C.byref(bad)) == 0
+    assert bad.value == 0
+    # the hook does see a wrong root: outside the window (denormal results' neighbourhood) the sequence is not exact
+    assert gpu_lib.pt_debug_sqrt_check(C.c_float(2.0 ** -126), C.c_float(2.0 ** -120), C.byref(bad)) == 0
+    assert bad.value > 0
+
+
 def test_fixed_point_sum_matches_big_integer_arithmetic(gpu_lib):
     rng = np.random.default_rng(1)
     cases = [
