@@ -282,6 +282,31 @@ def test_subtree_walk_bounds_only_choose_the_search(gpu_lib, case, walk, monkeyp
     assert len(np.unique(gpu["trace"]["reach0"])) > 3
 
 
+@pytest.mark.parametrize("shape", ["mixed-300", "perturb-only-700", "mixed-1000-one-wave", "mixed-10000", "drifted-cloud"])
+def test_untraced_run_ends_where_the_oracle_does(gpu_lib, shape):
+    """Without a step trace the kernels take the paths they take in production (no per-step record, the early rejection
+    of a removal that is bound to lose a node): final states, costs, accepted counts and swap decisions are the oracle's."""
+    mode, block = nt.MUT_ADAPTIVE, 0
+    if shape == "mixed-300":
+        n, T, G, iters, f = 300, 6, 2, 500, 34
+    elif shape == "perturb-only-700":
+        n, T, G, iters, f, mode = 700, 5, 1, 600, 52, nt.MUT_PERTURB_ONLY
+    elif shape == "mixed-1000-one-wave":
+        n, T, G, iters, f, block = 1000, 4, 2, 400, 63, 64
+    elif shape == "mixed-10000":
+        n, T, G, iters, f = 10000, 4, 1, 450, 200
+    else:
+        n, T, G, iters, f = 400, 4, 1, 500, 40
+    wl = wlm.graph_workload("untraced-" + shape, n, T, G, index=n)
+    if shape == "drifted-cloud":        # far from the origin: coordinates and centroid lose low bits
+        wl["pos"][:] += np.array([900.0, -350.0, 120.0], np.float32)
+    gpu = pu.gpu_run(wl, iters, f, seed="untraced-" + shape, trace=False, mutation_mode=mode, block_threads=block,
+                     chunks=[iters // 3, iters - iters // 3])
+    orc = pu.oracle_run(wl, iters, f, seed="untraced-" + shape, mutation_mode=mode, threads=4)
+    pu.assert_same_run(wl, gpu, orc, iters, trace=False)
+    assert np.array_equal(gpu["terms"][:, :, 6], gpu["cost"]), "the tracked cost is not a from-scratch evaluation of the final state"
+
+
 @pytest.mark.parametrize("block", [512, 768, 1024])
 def test_trace_parity_incremental_kernel_variants(gpu_lib, block):
     """The incremental kernel holds 24, 32 or 48 edges per thread depending on the workgroup size."""
