@@ -51,4 +51,6 @@ for half, sel in (("slots above 2.0", wl["temperatures"][0][slots[order]] > 2.0)
         c, t = counts[sel, k].sum(), ticks[sel, k].sum()
         if c:
             print(f"   {nm:24s} {100 * c / counts[sel].sum():5.1f} % of the steps, {t / c:8.0f} ticks each, {100 * t / ticks[sel].sum():5.1f} % of the time")
+w = st[:, 7].sum() / max(st[:, 15].sum(), 1.0)
+print(f"the walk through the lists (delta_list_search): {int(st[:, 15].sum())} calls, {w:.0f} ticks each")
 eng.close()
