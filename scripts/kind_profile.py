@@ -52,5 +52,7 @@ for half, sel in (("slots above 2.0", wl["temperatures"][0][slots[order]] > 2.0)
         if c:
             print(f"   {nm:24s} {100 * c / counts[sel].sum():5.1f} % of the steps, {t / c:8.0f} ticks each, {100 * t / ticks[sel].sum():5.1f} % of the time")
 w = st[:, 7].sum() / max(st[:, 15].sum(), 1.0)
-print(f"the walk through the lists (delta_list_search): {int(st[:, 15].sum())} calls, {w:.0f} ticks each")
+calls = max(st[:, 15].sum(), 1.0)
+print(f"the walk through the lists (delta_list_search): {int(st[:, 15].sum())} calls, {w:.0f} ticks each, "
+      f"{st[:, 6].sum() / calls:.1f} rounds down the tree and {st[:, 14].sum() / calls:.1f} rounds of label propagation per call")
 eng.close()
